@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE's own hot-path modules (dev container only).
+
+    python tests/golden/gen_golden.py            # writes tests/golden/*.npz
+
+What runs: the unmodified reference sources under /root/reference/pocket_tts/{modules,models/mimi.py,
+utils/config.py}: `StreamingTransformer` (FlowLM backbone: LayerNorm, packed QKV, RoPE, linear KV
+cache, SDPA, FFN), `SimpleMLPAdaLN` (flow head), `MimiModel.decode_from_latent` (upsample,
+decoder transformer, SEANet decoder), `init_states` / `increment_steps`.
+
+How it is imported: `pocket_tts/__init__.py` only activates the `beartype` runtime type checker,
+which is not installed here and is never stood in for.  This script registers an empty package
+object for `pocket_tts` whose `__path__` points at the reference directory, so the sub-modules above
+import from where they lie, unmodified, without executing that `__init__`.  `models/flow_lm.py` and
+`models/tts_model.py` import `beartype.typing` and therefore are NOT imported here; the few lines of
+glue they add around these modules (BOS substitution, input_linear, out_norm, EOS head, Euler
+`lsd_decode` loop: `flow_lm.py:19-40,121-139`) are re-stated in `_flow_lm_step` below with torch ops,
+flagged "glue" in the fixture metadata.  The companion script gen_golden_e2e.py covers those two
+files end to end.
+
+Weights are synthetic (pocket_tts_amd/weights.py; a pure function of seed/name/shape) because the
+shipped checkpoints are `hf://` downloads and there is no network.  Nothing from /root/reference is
+copied: fixtures hold only inputs and outputs (numbers).
+"""
+
+from __future__ import annotations
+
+import argparse
+import importlib
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parents[2]
+REF = Path("/root/reference")
+sys.path.insert(0, str(REPO))
+
+from pocket_tts_amd.config import Config, config_to_dict, named_config  # noqa: E402
+from pocket_tts_amd.weights import generate_tensor  # noqa: E402
+
+
+def import_reference_modules():
+    pkg = types.ModuleType("pocket_tts")
+    pkg.__path__ = [str(REF / "pocket_tts")]
+    sys.modules["pocket_tts"] = pkg
+    mods = {}
+    for name in [
+        "pocket_tts.modules.stateful_module",
+        "pocket_tts.modules.mimi_transformer",
+        "pocket_tts.modules.mlp",
+        "pocket_tts.modules.seanet",
+        "pocket_tts.modules.dummy_quantizer",
+        "pocket_tts.models.mimi",
+        "pocket_tts.utils.config",
+    ]:
+        mods[name.rsplit(".", 1)[-1]] = importlib.import_module(name)
+    return mods
+
+
+def load_synth(module: torch.nn.Module, prefix: str, seed: int):
+    sd = module.state_dict()
+    new = {k: torch.from_numpy(generate_tensor(prefix + k, tuple(v.shape), seed)) for k, v in sd.items()}
+    module.load_state_dict(new, strict=True)
+    return {prefix + k: v.numpy() for k, v in new.items()}
+
+
+def stamp_names(top: torch.nn.Module, StatefulModule):
+    # reference tts_model.py:224-228
+    for name, m in top.named_modules():
+        if isinstance(m, StatefulModule):
+            m._module_absolute_name = name
+
+
+def build_reference(cfg: Config, mods, seed: int):
+    """Reference modules, built from the reference's pydantic config, loaded with synthetic weights."""
+    rcfg = mods["config"].Config(**config_to_dict(cfg))
+    SM = mods["stateful_module"].StatefulModule
+    tr = mods["mimi_transformer"].StreamingTransformer.from_pydantic_config(rcfg.flow_lm.transformer)
+    d = rcfg.flow_lm.transformer.d_model
+    ldim = rcfg.mimi.quantizer.dimension
+    flow_net = mods["mlp"].SimpleMLPAdaLN.from_pydantic_config(rcfg.flow_lm, ldim, d)
+    # A bare container so that state_dict names match `flow_lm.*` of the checkpoint
+    class FlowLMParts(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.transformer = tr
+            self.flow_net = flow_net
+            self.input_linear = torch.nn.Linear(ldim, d, bias=False)
+            self.out_norm = torch.nn.LayerNorm(d, eps=1e-5)
+            self.out_eos = torch.nn.Linear(d, 1)
+            self.bos_emb = torch.nn.Parameter(torch.zeros(ldim))
+            self.register_buffer("emb_std", torch.ones(ldim))
+            self.register_buffer("emb_mean", torch.zeros(ldim))
+
+    lm = FlowLMParts().eval()
+    W = load_synth(lm, "flow_lm.", seed)
+    stamp_names(lm, SM)
+
+    mc = rcfg.mimi.model_dump()
+    seanet = mods["seanet"]
+    enc = seanet.SEANetEncoder(**mc["seanet"])
+    dec = seanet.SEANetDecoder(**mc["seanet"])
+    PT = mods["mimi_transformer"].ProjectedTransformer
+    mimi = mods["mimi"].MimiModel(
+        enc, dec, mods["dummy_quantizer"].DummyQuantizer(**mc["quantizer"]),
+        channels=mc["channels"], sample_rate=mc["sample_rate"], frame_rate=mc["frame_rate"],
+        encoder_frame_rate=mc["sample_rate"] / enc.hop_length,
+        inner_dim=mc["inner_dim"], outer_dim=mc["outer_dim"],
+        encoder_transformer=PT(**mc["transformer"]), decoder_transformer=PT(**mc["transformer"]),
+    ).eval()  # construction as reference tts_model.py:164-186
+    W.update(load_synth(mimi, "mimi.", seed))
+    stamp_names(mimi, SM)
+    return lm, mimi, W
+
+
+@torch.no_grad()
+def _flow_lm_step(lm, state, text_emb, seq, mods, lsd_steps, noise, eos_threshold):
+    """GLUE restated from reference flow_lm.py:121-139,141-157 and tts_model.py:340-345."""
+    seq = torch.where(torch.isnan(seq), lm.bos_emb, seq)
+    x = torch.cat([text_emb, lm.input_linear(seq)], dim=1)
+    out = lm.out_norm(lm.transformer(x, state))
+    mods["stateful_module"].increment_steps(lm, state, increment=x.shape[1])
+    if seq.shape[1] == 0:
+        return None
+    c = out[:, -1]
+    logit = lm.out_eos(c)
+    cur = noise.clone()
+    for i in range(lsd_steps):
+        s = i / lsd_steps
+        t = (i + 1) / lsd_steps
+        v = lm.flow_net(c, s * torch.ones_like(cur[..., :1]), t * torch.ones_like(cur[..., :1]), cur)
+        cur = cur + v / lsd_steps
+    return cur, logit[:, 0], logit[:, 0] > eos_threshold, c
+
+
+@torch.no_grad()
+def gen_case(name: str, cfg: Config, mods, seed: int, B: int, Tv: int, Tt: int, n_steps: int,
+             n_frames: int, lsd_steps: int, with_noise: bool, taps: bool):
+    torch.manual_seed(1234)
+    lm, mimi, _ = build_reference(cfg, mods, seed)
+    d = cfg.flow_lm.transformer.d_model
+    ldim = cfg.mimi.quantizer.dimension
+    out: dict = {}
+    g = torch.Generator().manual_seed(seed + 17)
+    voice = torch.randn(B, Tv, d, generator=g) * 0.1
+    text = torch.randn(B, Tt, d, generator=g)
+    noise = torch.randn(n_steps, B, ldim, generator=g) * (0.7 ** 0.5) if with_noise else torch.zeros(n_steps, B, ldim)
+    out["voice_emb"], out["text_emb"], out["noise"] = voice.numpy(), text.numpy(), noise.numpy()
+
+    init_states = mods["stateful_module"].init_states
+    state = init_states(lm, B, Tv + Tt + n_steps)
+    empty_seq = torch.zeros(B, 0, ldim)
+    empty_txt = torch.zeros(B, 0, d)
+    _flow_lm_step(lm, state, voice, empty_seq, mods, lsd_steps, None, -4.0)
+    _flow_lm_step(lm, state, text, empty_seq, mods, lsd_steps, None, -4.0)
+    k0 = "transformer.layers.0.self_attn"
+    kl = f"transformer.layers.{cfg.flow_lm.transformer.num_layers - 1}.self_attn"
+    out["kv_after_prefill_l0"] = state[k0]["cache"][:, :, : Tv + Tt].numpy().copy()
+    out["kv_after_prefill_last"] = state[kl]["cache"][:, :, : Tv + Tt].numpy().copy()
+    x = torch.full((B, 1, ldim), float("nan"))
+    lat, logits, conds = [], [], []
+    for i in range(n_steps):
+        cur, logit, is_eos, c = _flow_lm_step(lm, state, empty_txt, x, mods, lsd_steps, noise[i], -4.0)
+        lat.append(cur.numpy().copy())
+        logits.append(logit.numpy().copy())
+        conds.append(c.numpy().copy())
+        x = cur[:, None, :]
+    out["latents"] = np.stack(lat)
+    out["eos_logits"] = np.stack(logits)
+    out["conds"] = np.stack(conds)
+    out["kv_final_l0_last_pos"] = state[k0]["cache"][:, :, Tv + Tt + n_steps - 1].numpy().copy()
+    out["offset_final"] = np.array(int(state[k0]["offset"][0]))
+
+    # single-call module checks (no glue at all): transformer stack on a fresh state, flow_net
+    st2 = init_states(lm, B, 8)
+    xin = torch.randn(B, 5, d, generator=g)
+    out["tr_in"] = xin.numpy()
+    out["tr_out"] = lm.transformer(xin, st2).numpy().copy()
+    cc = torch.randn(B, d, generator=g)
+    xx = torch.randn(B, ldim, generator=g)
+    out["fn_c"], out["fn_x"] = cc.numpy(), xx.numpy()
+    for tag, (s, t) in {"01": (0.0, 1.0), "0h": (0.0, 0.5), "h1": (0.5, 1.0)}.items():
+        o = lm.flow_net(cc, s * torch.ones(B, 1), t * torch.ones(B, 1), xx)
+        out[f"fn_out_{tag}"] = o.numpy().copy()
+
+    # Mimi decode: reference tts_model.py:444-455 (de-normalise, quantizer, decode, +16 steps)
+    mst = init_states(mimi, B, n_frames * cfg.upsample_stride)
+    lat_in = torch.from_numpy(out["latents"][:n_frames]) if n_frames <= n_steps else None
+    if lat_in is None:
+        lat_in = torch.randn(n_frames, B, ldim, generator=g)
+    out["mimi_latents"] = lat_in.numpy()
+    hooks, rec = [], {}
+    if taps:
+        def mk(key):
+            def hook(_m, _i, o):
+                rec.setdefault(key, []).append((o[0] if isinstance(o, (list, tuple)) else o).numpy().copy())
+            return hook
+        hooks.append(mimi.upsample.register_forward_hook(mk("upsample")))
+        hooks.append(mimi.decoder_transformer.register_forward_hook(mk("dec_tr")))
+        for idx, layer in enumerate(mimi.decoder.model):
+            if not isinstance(layer, torch.nn.ELU):
+                hooks.append(layer.register_forward_hook(mk(f"seanet{idx}")))
+    pcm = []
+    for f in range(n_frames):
+        z = lat_in[f][:, None, :] * lm.emb_std + lm.emb_mean
+        q = mimi.quantizer(z.transpose(-1, -2))
+        a = mimi.decode_from_latent(q, mst)
+        mods["stateful_module"].increment_steps(mimi, mst, increment=cfg.upsample_stride)
+        pcm.append(a[:, 0].numpy().copy())
+    for h in hooks:
+        h.remove()
+    out["pcm"] = np.stack(pcm)
+    for k, v in rec.items():
+        out["tap_" + k] = np.stack(v[: min(3, n_frames)])
+    meta = dict(config=name, seed=seed, B=B, Tv=Tv, Tt=Tt, n_steps=n_steps, n_frames=n_frames,
+                lsd_steps=lsd_steps, with_noise=with_noise,
+                glue="flow_lm.py:121-139 restated in gen_golden.py:_flow_lm_step")
+    out["meta"] = np.array(repr(meta))
+    return out
+
+
+CASES = {
+    # name: (config, B, Tv, Tt, n_steps, n_frames, lsd_steps, with_noise, taps)
+    "tiny_b2": ("tiny", 2, 5, 3, 12, 6, 1, False, True),
+    "tiny_b3_noise_lsd2": ("tiny", 3, 4, 2, 6, 4, 2, True, False),
+    "en100m_b1": ("en100m", 1, 9, 7, 8, 4, 1, False, False),
+    "en100m_b2_noise": ("en100m", 2, 6, 5, 5, 3, 1, True, False),
+    "24l_b1": ("24l", 1, 6, 4, 3, 2, 1, False, False),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    torch.set_num_threads(8)
+    mods = import_reference_modules()
+    outdir = Path(__file__).parent
+    for case, (cname, B, Tv, Tt, ns, nf, lsd, wn, taps) in CASES.items():
+        if args.only and case not in args.only:
+            continue
+        cfg = named_config(cname)
+        out = gen_case(cname, cfg, mods, args.seed, B, Tv, Tt, ns, nf, lsd, wn, taps)
+        path = outdir / f"golden_{case}.npz"
+        np.savez_compressed(path, **out)
+        print(f"{case}: wrote {path} ({path.stat().st_size/1e3:.0f} kB); "
+              f"eos_logits[:, 0]={np.round(out['eos_logits'][:, 0], 2)}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,110 @@
+"""Pin the numpy oracle (oracle/np_oracle.py) to the golden vectors produced by the reference's
+own modules (tests/golden/gen_golden.py).  CPU only.
+
+Tolerance: both sides are fp32 with different summation orders (ATen/mkldnn vs numpy/OpenBLAS);
+we require max-abs error <= 2e-4 on O(1) quantities after up to 12 autoregressive steps and
+EXACT equality of the EOS decisions at the default threshold and at the median logit.
+"""
+
+import numpy as np
+import pytest
+
+from conftest import synth_weights
+from oracle import np_oracle as O
+
+ATOL = 2e-4
+
+CASES = ["tiny_b2", "tiny_b3_noise_lsd2", "en100m_b1", "en100m_b2_noise", "24l_b1"]
+
+
+def _maxerr(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+def _run_lm(g):
+    m = g["meta"]
+    cfg, W = synth_weights(m["config"], m["seed"])
+    lm = O.FlowLM(cfg, W)
+    B = m["B"]
+    st = lm.init_state(B, m["Tv"] + m["Tt"] + m["n_steps"])
+    lm.prefill(st, g["voice_emb"])
+    lm.prefill(st, g["text_emb"])
+    kv0 = st[0]["cache"][:, :, : m["Tv"] + m["Tt"]].copy()
+    kvl = st[-1]["cache"][:, :, : m["Tv"] + m["Tt"]].copy()
+    x = np.full((B, lm.ldim), np.nan, np.float32)
+    lat, logits = [], []
+    for i in range(m["n_steps"]):
+        noise = g["noise"][i] if m["with_noise"] else None
+        x, logit, _ = lm.decode_step(st, x, noise, m["lsd_steps"], -4.0)
+        lat.append(x.copy())
+        logits.append(logit.copy())
+    return lm, st, kv0, kvl, np.stack(lat), np.stack(logits)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_flow_lm_matches_reference(golden, case):
+    g = golden(case)
+    m = g["meta"]
+    lm, st, kv0, kvl, lat, logits = _run_lm(g)
+    assert _maxerr(kv0, g["kv_after_prefill_l0"]) < ATOL
+    assert _maxerr(kvl, g["kv_after_prefill_last"]) < ATOL
+    assert _maxerr(lat, g["latents"]) < ATOL
+    assert _maxerr(logits, g["eos_logits"]) < 5e-4
+    # EOS decision sequence: exact at the reference default and at the median logit
+    for thr in (-4.0, float(np.median(g["eos_logits"]))):
+        margin = np.abs(g["eos_logits"] - thr).min()
+        if margin > 1e-3:
+            assert np.array_equal(logits > thr, g["eos_logits"] > thr)
+    assert st[0]["offset"] == int(g["offset_final"])
+    last = m["Tv"] + m["Tt"] + m["n_steps"] - 1
+    assert _maxerr(st[0]["cache"][:, :, last], g["kv_final_l0_last_pos"]) < ATOL
+
+
+@pytest.mark.parametrize("case", ["tiny_b2", "en100m_b1"])
+def test_transformer_stack_single_call(golden, case):
+    g = golden(case)
+    m = g["meta"]
+    cfg, W = synth_weights(m["config"], m["seed"])
+    lm = O.FlowLM(cfg, W)
+    st = lm.init_state(m["B"], 8)
+    x = g["tr_in"].astype(np.float32)
+    for i in range(lm.L):
+        x = O.transformer_layer(x, st[i], W, f"flow_lm.transformer.layers.{i}", lm.H, None, lm.max_period)
+    assert _maxerr(x, g["tr_out"]) < ATOL
+
+
+@pytest.mark.parametrize("case", ["tiny_b2", "en100m_b1"])
+def test_flow_net_single_call(golden, case):
+    g = golden(case)
+    m = g["meta"]
+    cfg, W = synth_weights(m["config"], m["seed"])
+    lm = O.FlowLM(cfg, W)
+    B = m["B"]
+    for tag, (s, t) in {"01": (0.0, 1.0), "0h": (0.0, 0.5), "h1": (0.5, 1.0)}.items():
+        o = lm.flow_net(g["fn_c"], np.full((B, 1), s, np.float32), np.full((B, 1), t, np.float32), g["fn_x"])
+        assert _maxerr(o, g[f"fn_out_{tag}"]) < ATOL, tag
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_mimi_decode_matches_reference(golden, case):
+    g = golden(case)
+    m = g["meta"]
+    cfg, W = synth_weights(m["config"], m["seed"])
+    dec = O.MimiDecoder(cfg, W)
+    st = dec.init_state(m["B"], m["n_frames"])
+    for f in range(m["n_frames"]):
+        taps = {}
+        pcm = dec.decode(st, g["mimi_latents"][f], taps)
+        assert pcm.shape == (m["B"], cfg.frame_samples)
+        assert _maxerr(pcm, g["pcm"][f]) < ATOL, f"frame {f}"
+        if f < 3:
+            for k, v in taps.items():
+                gk = "tap_" + k
+                if gk in g:
+                    assert _maxerr(v, g[gk][f]) < ATOL, f"{k} frame {f}"
+
+
+def test_golden_covers_first_frame_zero_state(golden):
+    """Frame 0 exercises the zero-initialised `previous`/`partial` carries."""
+    g = golden("tiny_b2")
+    assert "tap_upsample" in g and "tap_seanet0" in g and g["tap_seanet0"].shape[0] == 3
