@@ -1,0 +1,125 @@
+/*
+ * ptts.h -- C ABI of the MI355X (gfx950) Pocket-TTS decode hot path.
+ *
+ * The reference (kyutai-labs/pocket-tts) is pure Python and has no FFI; the seam this
+ * library replaces is the set of Python call sites listed per entry point below
+ * (paths relative to the reference checkout).  All pointers named `d_*` are DEVICE
+ * pointers to fp32 data (e.g. torch `tensor.data_ptr()` on a ROCm device); `h_*` are host
+ * pointers.  `stream` is a `hipStream_t` passed as `void*` (NULL = the engine's own
+ * stream).  Every function returns 0 on success or a negative error code;
+ * `ptts_last_error()` returns the message.  No exceptions cross the ABI.  Handles are not
+ * re-entrant: one thread per handle at a time.
+ */
+#ifndef PTTS_H_
+#define PTTS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTTS_ABI_VERSION 1
+
+typedef struct ptts_engine ptts_engine;         /* weights + kernels for one GPU         */
+typedef struct ptts_lm_state ptts_lm_state;     /* FlowLM KV caches of B sequences       */
+typedef struct ptts_mimi_state ptts_mimi_state; /* Mimi streaming state of B sequences   */
+typedef struct ptts_graph ptts_graph;           /* a captured hipGraph of one step       */
+
+/* Model dimensions: pocket_tts/config/english.yaml:7-61 (schema utils/config.py:15-118). */
+typedef struct ptts_config {
+  int32_t d_model, num_heads, num_layers, ff_dim, ldim; /* flow_lm.transformer, quantizer.dimension */
+  int32_t flow_dim, flow_depth;                         /* flow_lm.flow                              */
+  float max_period;                                     /* flow_lm.transformer.max_period            */
+  int32_t m_dim, m_heads, m_layers, m_ff, m_context;    /* mimi.transformer (d_model == seanet dim)  */
+  float m_max_period;
+  int32_t n_filters, ratios[3], kernel_size, res_kernel_size, last_kernel_size, compress;
+  int32_t upsample_stride;                              /* encoder_frame_rate / frame_rate = 16      */
+} ptts_config;
+
+/* One checkpoint tensor, name as in TTSModel.state_dict() (tts_model.py:206-210). */
+typedef struct ptts_tensor {
+  const char *name;
+  const float *d_data;
+  int64_t numel;
+} ptts_tensor;
+
+int ptts_abi_version(void);
+const char *ptts_last_error(void);
+
+/* Builds the engine: packs the checkpoint tensors it needs into MFMA-fragment order on
+ * `device`.  Replaces TTSModel._from_pydantic_config_with_weights (tts_model.py:129-230)
+ * for the decode-side modules.  The caller may free the source tensors afterwards. */
+int ptts_create(const ptts_config *cfg, const ptts_tensor *tensors, int32_t n_tensors, int32_t device,
+                ptts_engine **out);
+void ptts_destroy(ptts_engine *e);
+
+/* ---- FlowLM state: init_states(flow_lm, B, T) (stateful_module.py:7-16, transformer.py:46-57) */
+int ptts_lm_state_create(ptts_engine *e, int32_t batch, int32_t t_cap, ptts_lm_state **out);
+void ptts_lm_state_destroy(ptts_lm_state *s);
+/* zero offsets (fresh init_states) */
+int ptts_lm_state_reset(ptts_lm_state *s, void *stream);
+/* Import / export one layer in the reference layout cache f32[2, src_batch, t, H, 64] (device) with
+ * `t` valid positions (transformer.py:32-36; voice files tts_model.py:1047-1072).  On import,
+ * src_batch == 1 broadcasts to every row of the state, and every row's offset is set to t. */
+int ptts_lm_state_import(ptts_lm_state *s, int32_t layer, const float *d_cache, int32_t src_batch,
+                         int32_t t, void *stream);
+int ptts_lm_state_export(ptts_lm_state *s, int32_t layer, float *d_cache, int32_t t, void *stream);
+/* dst <- src (replaces copy.deepcopy(model_state), tts_model.py:637-638); src batch 1 broadcasts */
+int ptts_lm_state_copy(ptts_lm_state *dst, const ptts_lm_state *src, void *stream);
+/* offsets of all rows to host (transformer.py:14 `.item()`; synchronises the stream) */
+int ptts_lm_state_offsets(ptts_lm_state *s, int32_t *h_offsets, void *stream);
+
+/* Text or voice conditioning d_emb f32[B, t, d_model] run through every layer; only the KV cache
+ * is kept.  Replaces _run_flow_lm_and_increment_step(text_tokens=.. | audio_conditioning=..)
+ * (tts_model.py:317-346, call sites :723, :899). */
+int ptts_lm_prefill(ptts_engine *e, ptts_lm_state *s, const float *d_emb, int32_t t, void *stream);
+
+/* One autoregressive step = _run_flow_lm_and_increment_step(backbone_input_latents=..)
+ * (tts_model.py:758-760 -> flow_lm.py:96-139).
+ *   d_latent_in  f32[B, ldim]  rows of NaN mean BOS; NULL = previous step's output (or BOS after reset)
+ *   d_noise      f32[B, ldim]  starting point of the LSD flow (flow_lm.py:131-137); NULL = zeros (temp 0)
+ *   d_latent_out f32[B, ldim], d_eos_logit f32[B], d_is_eos u8[B] (logit > eos_threshold); any may be NULL */
+int ptts_lm_decode_step(ptts_engine *e, ptts_lm_state *s, const float *d_latent_in, const float *d_noise,
+                        int32_t lsd_steps, float eos_threshold, float *d_latent_out, float *d_eos_logit,
+                        uint8_t *d_is_eos, void *stream);
+/* device pointer of the state's own copy of the latest latent f32[B, ldim] */
+const float *ptts_lm_latent_ptr(ptts_lm_state *s);
+
+/* ---- Mimi streaming decode: init_states(mimi, B, ..) + _decode_audio_worker body
+ *      (tts_model.py:444-455 -> mimi.py:89-94) */
+int ptts_mimi_state_create(ptts_engine *e, int32_t batch, ptts_mimi_state **out);
+void ptts_mimi_state_destroy(ptts_mimi_state *s);
+int ptts_mimi_state_reset(ptts_mimi_state *s, void *stream);
+/* d_latent f32[B, ldim] (normalised FlowLM output) -> d_pcm f32[B, frame_samples]; includes the
+ * emb_std/emb_mean de-normalisation, the quantizer 1x1 conv and increment_steps(mimi, 16). */
+int ptts_mimi_decode(ptts_engine *e, ptts_mimi_state *s, const float *d_latent, float *d_pcm, void *stream);
+
+/* ---- hipGraph capture of one step (north star: "each decode step hipGraph-captured").
+ * The captured step uses the same argument pointers on every launch. */
+int ptts_graph_capture_lm_step(ptts_engine *e, ptts_lm_state *s, const float *d_noise, int32_t lsd_steps,
+                               float eos_threshold, float *d_latent_out, float *d_eos_logit,
+                               uint8_t *d_is_eos, ptts_graph **out);
+int ptts_graph_capture_mimi(ptts_engine *e, ptts_mimi_state *s, const float *d_latent, float *d_pcm,
+                            ptts_graph **out);
+int ptts_graph_launch(ptts_graph *g, void *stream);
+void ptts_graph_destroy(ptts_graph *g);
+
+/* ---- utilities */
+int ptts_sync(ptts_engine *e, void *stream);
+void *ptts_engine_stream(ptts_engine *e);
+/* HIP-event timing on `stream` (bench.py measures on the stream the kernels run on) */
+int ptts_timer_start(ptts_engine *e, void *stream);
+int ptts_timer_stop_ms(ptts_engine *e, void *stream, float *h_ms);
+/* Test hook: copies an internal activation buffer, converted to row-major f32[rows, cols], to
+ * d_out (capacity in floats).  Names: see DESIGN.md.  Returns rows*cols or <0. */
+int64_t ptts_debug_read(ptts_engine *e, void *state, int32_t is_mimi, const char *name, float *d_out,
+                        int64_t capacity, int32_t *rows, int32_t *cols, void *stream);
+/* Packed weight bytes streamed by one LM decode step / one Mimi frame (roofline accounting) */
+int64_t ptts_lm_weight_bytes(ptts_engine *e);
+int64_t ptts_mimi_weight_bytes(ptts_engine *e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTTS_H_ */

@@ -1,0 +1,121 @@
+"""ctypes binding of libptts.so (C ABI: include/ptts.h).  Fails loudly when the HIP library is
+missing: there is no CPU fallback for the hot path."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "libptts.so"
+SRC = PKG / "csrc" / "ptts.hip"
+HEADER = PKG.parent / "include" / "ptts.h"
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result",
+               "-shared", "-fPIC"]
+
+
+class PttsConfig(C.Structure):
+    _fields_ = [
+        ("d_model", C.c_int32), ("num_heads", C.c_int32), ("num_layers", C.c_int32), ("ff_dim", C.c_int32),
+        ("ldim", C.c_int32), ("flow_dim", C.c_int32), ("flow_depth", C.c_int32), ("max_period", C.c_float),
+        ("m_dim", C.c_int32), ("m_heads", C.c_int32), ("m_layers", C.c_int32), ("m_ff", C.c_int32),
+        ("m_context", C.c_int32), ("m_max_period", C.c_float),
+        ("n_filters", C.c_int32), ("ratios", C.c_int32 * 3), ("kernel_size", C.c_int32),
+        ("res_kernel_size", C.c_int32), ("last_kernel_size", C.c_int32), ("compress", C.c_int32),
+        ("upsample_stride", C.c_int32),
+    ]
+
+
+class PttsTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("d_data", C.c_void_p), ("numel", C.c_int64)]
+
+
+# every symbol include/ptts.h declares: (restype, argtypes)
+_P = C.c_void_p
+PROTOTYPES = {
+    "ptts_abi_version": (C.c_int, []),
+    "ptts_last_error": (C.c_char_p, []),
+    "ptts_create": (C.c_int, [C.POINTER(PttsConfig), C.POINTER(PttsTensor), C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "ptts_destroy": (None, [_P]),
+    "ptts_lm_state_create": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "ptts_lm_state_destroy": (None, [_P]),
+    "ptts_lm_state_reset": (C.c_int, [_P, _P]),
+    "ptts_lm_state_import": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, _P]),
+    "ptts_lm_state_export": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P]),
+    "ptts_lm_state_copy": (C.c_int, [_P, _P, _P]),
+    "ptts_lm_state_offsets": (C.c_int, [_P, C.POINTER(C.c_int32), _P]),
+    "ptts_lm_prefill": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
+    "ptts_lm_decode_step": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_float, _P, _P, _P, _P]),
+    "ptts_lm_latent_ptr": (_P, [_P]),
+    "ptts_mimi_state_create": (C.c_int, [_P, C.c_int32, C.POINTER(_P)]),
+    "ptts_mimi_state_destroy": (None, [_P]),
+    "ptts_mimi_state_reset": (C.c_int, [_P, _P]),
+    "ptts_mimi_decode": (C.c_int, [_P, _P, _P, _P, _P]),
+    "ptts_graph_capture_lm_step": (C.c_int, [_P, _P, _P, C.c_int32, C.c_float, _P, _P, _P, C.POINTER(_P)]),
+    "ptts_graph_capture_mimi": (C.c_int, [_P, _P, _P, _P, C.POINTER(_P)]),
+    "ptts_graph_launch": (C.c_int, [_P, _P]),
+    "ptts_graph_destroy": (None, [_P]),
+    "ptts_sync": (C.c_int, [_P, _P]),
+    "ptts_engine_stream": (_P, [_P]),
+    "ptts_timer_start": (C.c_int, [_P, _P]),
+    "ptts_timer_stop_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
+    "ptts_debug_read": (C.c_int64, [_P, _P, C.c_int32, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_int32), _P]),
+    "ptts_lm_weight_bytes": (C.c_int64, [_P]),
+    "ptts_mimi_weight_bytes": (C.c_int64, [_P]),
+}
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile csrc/ptts.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    deps = [SRC, SRC.parent / "ptts_kernels.h", HEADER]
+    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, *HIPCC_FLAGS, "-o", str(LIB_PATH), str(SRC)]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads libptts.so; raises if it is absent (the product has no other path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  The MI355X hot path has no CPU fallback."
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ptts_abi_version() != 1:
+        raise RuntimeError("libptts ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+class PttsError(RuntimeError):
+    pass
+
+
+def check(rc: int):
+    if rc < 0:
+        msg = load().ptts_last_error().decode()
+        if rc == -5:
+            raise ValueError(msg)  # capacity errors mirror the reference's ValueError family
+        raise PttsError(f"libptts error {rc}: {msg}")
+    return rc

@@ -1,0 +1,1011 @@
+// Host side of libptts: engine construction (weight packing), FlowLM / Mimi step orchestration,
+// hipGraph capture and the C ABI declared in include/ptts.h.
+#include "ptts_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ptts.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(x)                                                                                      \
+  do {                                                                                                 \
+    hipError_t e_ = (x);                                                                               \
+    if (e_ != hipSuccess)                                                                              \
+      return fail(-2, std::string(#x) + ": " + hipGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
+  } while (0)
+#define CHK(x)            \
+  do {                    \
+    int r_ = (x);         \
+    if (r_ < 0) return r_; \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------------------------------------
+struct Lin {  // one packed weight matrix
+  float *w = nullptr, *bias = nullptr;
+  int N = 0, NT = 0, C = 0, CF = 0, ntaps = 1, KF = 0;
+  int cout = 0, stride = 0;  // transposed-conv view
+  size_t bytes() const { return (size_t)NT * KF * 1024; }
+};
+
+struct TrLayer {
+  float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *ls1 = nullptr, *ls2 = nullptr;
+  Lin qkv, out, ff1, ff2;
+};
+
+struct ptts_engine {
+  ptts_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<void *> allocs;
+  std::map<std::string, const ptts_tensor *> tmap;
+  // FlowLM
+  float *bos = nullptr, *freq_lm = nullptr;
+  Lin in_linear;
+  std::vector<TrLayer> lm;
+  float *outnorm_w, *outnorm_b;
+  Lin head, adaln, input_proj, fin;
+  struct Res { float *ln_w, *ln_b; Lin l0, l2; };
+  std::vector<Res> res;
+  Lin te_l0[2], te_l2[2];
+  float *te_freqs[2], *te_alpha[2];
+  std::map<int, float *> tcomb;  // lsd_steps -> [S][flow_dim]
+  float *te_scratch = nullptr;
+  // Mimi
+  float *emb_std, *emb_mean, *up_w, *freq_mimi;
+  Lin quant;
+  std::vector<TrLayer> mm;
+  Lin conv0, convtr[3], res_a[3], res_b[3], conv_last;
+  int ring = 0;
+  int64_t lm_bytes = 0, mimi_bytes = 0;
+};
+
+struct Scratch {
+  float *x = nullptr, *h = nullptr, *ao = nullptr, *ff = nullptr, *q = nullptr, *part = nullptr;
+  int MT = 0, QB = 0, splits_cap = 0;
+};
+
+struct ptts_lm_state {
+  ptts_engine *e;
+  int B, cap, MT;
+  float *kv = nullptr;  // [L][2][B][H][cap][64]
+  int *offset = nullptr;
+  std::vector<int> h_off;
+  Scratch dec, pre;
+  // flow head scratch (FM) + io
+  float *xlat, *c, *ce, *mod, *latfm, *fx, *fh, *f1;
+  float *lat, *lat_prev;  // plain [B][ldim]
+  float *eos_logit;
+  uint8_t *is_eos;
+  size_t kv_plane() const { return (size_t)B * e->cfg.num_heads * cap * 64; }
+  float *K(int l) { return kv + (size_t)(2 * l) * kv_plane(); }
+  float *V(int l) { return kv + (size_t)(2 * l + 1) * kv_plane(); }
+};
+
+struct ptts_mimi_state {
+  ptts_engine *e;
+  int B, MTb, MT16;
+  int *frame = nullptr, *offset = nullptr;
+  int h_frame = 0;
+  float *kv = nullptr;  // [ML][2][B][H][ring][64]
+  float *zl, *zq, *u0, *u, *h, *ao, *ff, *q, *part, *tr_out;
+  long zq_stride, tr_stride;
+  int splits;
+  float *a0;
+  long a0_stride;
+  float *cbuf[3], *rbuf[3], *sbuf[3];
+  long c_stride[3], s_stride[3];
+  int rows[4];  // rows per sequence at each SEANet stage
+  float *pcm_dbg;
+  size_t kv_plane() const { return (size_t)B * e->cfg.m_heads * e->ring * 64; }
+  float *K(int l) { return kv + (size_t)(2 * l) * kv_plane(); }
+  float *V(int l) { return kv + (size_t)(2 * l + 1) * kv_plane(); }
+};
+
+struct ptts_graph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  ptts_lm_state *lm = nullptr;
+  ptts_mimi_state *mimi = nullptr;
+  hipStream_t cap_stream = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------------
+// allocation helpers
+// Zero-filled device allocation.  The fill is queued on `st` (the engine stream, which is
+// non-blocking and therefore NOT ordered against the null stream a plain hipMemset would use).
+static hipStream_t g_alloc_stream = nullptr;
+static int dalloc(ptts_engine *e, void **p, size_t bytes) {
+  if (bytes == 0) bytes = 256;
+  HIPCHK(hipMalloc(p, bytes));
+  HIPCHK(hipMemsetAsync(*p, 0, bytes, g_alloc_stream));
+  if (e) e->allocs.push_back(*p);
+  return 0;
+}
+template <typename T>
+static int dallocT(ptts_engine *e, T **p, size_t n) {
+  return dalloc(e, (void **)p, n * sizeof(T));
+}
+
+static const ptts_tensor *find_tensor(ptts_engine *e, const std::string &name, int64_t numel, int *err) {
+  auto it = e->tmap.find(name);
+  if (it == e->tmap.end()) {
+    *err = fail(-3, "missing tensor: " + name);
+    return nullptr;
+  }
+  if (numel >= 0 && it->second->numel != numel) {
+    *err = fail(-3, "tensor " + name + ": expected " + std::to_string(numel) + " elements, got " +
+                        std::to_string(it->second->numel));
+    return nullptr;
+  }
+  return it->second;
+}
+
+// copies a small fp32 vector (norm gains, biases, ...) into engine-owned memory, padded
+static int copy_vec(ptts_engine *e, const std::string &name, int64_t n, float **out, int64_t pad_to = 0) {
+  int err = 0;
+  const ptts_tensor *t = find_tensor(e, name, n, &err);
+  if (!t) return err;
+  CHK(dallocT(e, out, std::max<int64_t>(pad_to, n)));
+  HIPCHK(hipMemcpyAsync(*out, t->d_data, n * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+  return 0;
+}
+
+struct PackPart { std::string w, b; int N; };
+
+// packs one or several [N_i][C][ntaps] matrices (stacked along N) into one Lin
+static int pack_lin(ptts_engine *e, Lin *L, const std::vector<PackPart> &parts, int C, int ntaps, int mode = 0,
+                    int cout = 0, int stride = 0) {
+  if (C % 16) return fail(-4, "channel count must be a multiple of 16: " + parts[0].w);
+  int ntot = 0;
+  for (auto &p : parts) ntot += cdiv(p.N, 16);
+  L->NT = ntot;
+  L->C = C;
+  L->CF = C / 16;
+  L->ntaps = ntaps;
+  L->KF = L->CF * ntaps;
+  L->cout = cout;
+  L->stride = stride;
+  L->N = 0;
+  CHK(dallocT(e, &L->w, (size_t)L->NT * L->KF * 256));
+  bool any_bias = false;
+  for (auto &p : parts) any_bias |= !p.b.empty();
+  if (any_bias) CHK(dallocT(e, &L->bias, (size_t)L->NT * 16));
+  int nt_off = 0;
+  for (auto &p : parts) {
+    int err = 0;
+    const ptts_tensor *t = find_tensor(e, p.w, (int64_t)(mode == 0 ? p.N : (p.N / stride)) * C * (mode == 0 ? ntaps : 2 * stride), &err);
+    if (!t) return err;
+    int nt = cdiv(p.N, 16);
+    long total = (long)nt * L->KF * 256;
+    pack_weight_kernel<<<cdiv(total, 256), 256, 0, e->stream>>>(t->d_data, L->w, p.N, C, ntaps, mode, cout, stride,
+                                                                nt_off, L->KF, total);
+    if (any_bias) {
+      const float *bsrc = nullptr;
+      if (!p.b.empty()) {
+        const ptts_tensor *tb = find_tensor(e, p.b, mode == 0 ? p.N : cout, &err);
+        if (!tb) return err;
+        bsrc = tb->d_data;
+      }
+      pack_bias_kernel<<<cdiv(nt * 16, 256), 256, 0, e->stream>>>(bsrc, L->bias, p.N, mode, cout, nt_off * 16, nt * 16);
+    }
+    nt_off += nt;
+    L->N += p.N;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int pack_tr_layer(ptts_engine *e, TrLayer *T, const std::string &p, int d, int ff, bool ls) {
+  CHK(copy_vec(e, p + ".norm1.weight", d, &T->ln1_w));
+  CHK(copy_vec(e, p + ".norm1.bias", d, &T->ln1_b));
+  CHK(copy_vec(e, p + ".norm2.weight", d, &T->ln2_w));
+  CHK(copy_vec(e, p + ".norm2.bias", d, &T->ln2_b));
+  if (ls) {
+    CHK(copy_vec(e, p + ".layer_scale_1.scale", d, &T->ls1));
+    CHK(copy_vec(e, p + ".layer_scale_2.scale", d, &T->ls2));
+  }
+  CHK(pack_lin(e, &T->qkv, {{p + ".self_attn.in_proj.weight", "", 3 * d}}, d, 1));
+  CHK(pack_lin(e, &T->out, {{p + ".self_attn.out_proj.weight", "", d}}, d, 1));
+  CHK(pack_lin(e, &T->ff1, {{p + ".linear1.weight", "", ff}}, d, 1));
+  CHK(pack_lin(e, &T->ff2, {{p + ".linear2.weight", "", d}}, ff, 1));
+  return 0;
+}
+
+static int make_freq(ptts_engine *e, float **out, float max_period) {
+  // freqs = exp(ds * (-ln(max_period) * 2 / D)) in fp32, D = 64 (reference rope.py:28-29)
+  float h[32];
+  const float coef = (float)(-std::log((double)max_period) * 2.0 / 64.0);
+  for (int i = 0; i < 32; ++i) h[i] = std::exp((float)i * coef);
+  CHK(dallocT(e, out, 32));
+  HIPCHK(hipStreamSynchronize(g_alloc_stream));
+  HIPCHK(hipMemcpy(*out, h, sizeof(h), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM dispatch
+template <int TN, int TM, int WK, int WN, int WM>
+static void launch_cfg(hipStream_t st, const GemmArgs &a, int pre) {
+  dim3 grid(cdiv(a.NT, TN * WN), cdiv(a.MT, TM * WM));
+  dim3 block(64 * WK * WN * WM);
+  switch (pre) {
+    case PRE_NONE: gemm_kernel<TN, TM, WK, WN, WM, PRE_NONE><<<grid, block, 0, st>>>(a); break;
+    case PRE_ELU: gemm_kernel<TN, TM, WK, WN, WM, PRE_ELU><<<grid, block, 0, st>>>(a); break;
+    default: gemm_kernel<TN, TM, WK, WN, WM, PRE_ADDSILU><<<grid, block, 0, st>>>(a); break;
+  }
+}
+
+static void launch_gemm(hipStream_t st, const GemmArgs &a, int pre) {
+  if (a.MT <= 1) launch_cfg<1, 1, 8, 1, 1>(st, a, pre);
+  else if (a.MT == 2) launch_cfg<1, 2, 8, 1, 1>(st, a, pre);
+  else if (a.MT <= 4) launch_cfg<1, 4, 8, 1, 1>(st, a, pre);
+  else if (a.NT >= 4) launch_cfg<2, 4, 1, 2, 2>(st, a, pre);
+  else if (a.NT >= 2) launch_cfg<2, 4, 1, 1, 4>(st, a, pre);
+  else launch_cfg<1, 4, 1, 1, 4>(st, a, pre);
+}
+
+static GemmArgs mk_gemm(const Lin &L, const float *X, int XF, int MT, int M) {
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.W = L.w;
+  a.bias = L.bias;
+  a.NT = L.NT;
+  a.KF = L.KF;
+  a.CF = L.CF;
+  a.ntaps = L.ntaps;
+  a.X = X;
+  a.XF = XF;
+  a.MT = MT;
+  a.M = M;
+  a.T = 16;
+  a.epi = EPI_STORE;
+  a.act = ACT_NONE;
+  return a;
+}
+
+static void launch_ln(hipStream_t st, const float *X, long xds, int XF, float *Y, int YF, const float *w,
+                      const float *b, const float *shift, const float *scale, int SF, int KF, float eps, int MT,
+                      const int *par) {
+  LnArgs a;
+  a.X = X; a.Xdstride = xds; a.XF = XF; a.Y = Y; a.YF = YF; a.w = w; a.b = b;
+  a.shift = shift; a.scale = scale; a.SF = SF; a.KF = KF; a.eps = eps; a.par = par;
+  layernorm_kernel<<<MT, 256, 0, st>>>(a);
+}
+
+static int attn_splits(int base, int max_tiles) {
+  int s = std::max(1, 1024 / std::max(1, base));
+  return std::max(1, std::min(s, max_tiles));
+}
+
+// One pre-LN transformer layer on M rows (reference mimi_transformer.py:39-54, transformer.py:135-158)
+struct TrCtx {
+  int D, H, FF, MT, M, Tq, QB, cap, ring, ctx, splits;
+  float *x_in;       // residual stream input (FM, F = D/16)
+  float *x;          // residual stream after attention (may equal x_in)
+  float *x_out;      // residual stream output of the layer (dbl-buffered if out_ds != 0)
+  long out_ds;
+  const int *par;
+  float *h, *ao, *ff, *q, *part;
+  float *Kc, *Vc;
+  const int *offset;
+  const float *freq;
+};
+
+static void run_tr_layer(hipStream_t st, const TrLayer &T, const TrCtx &c) {
+  const int DF = c.D / 16;
+  launch_ln(st, c.x_in, 0, DF, c.h, DF, T.ln1_w, T.ln1_b, nullptr, nullptr, 0, DF, 1e-5f, c.MT, nullptr);
+  GemmArgs a = mk_gemm(T.qkv, c.h, DF, c.MT, c.M);
+  a.epi = EPI_QKV;
+  a.Q = c.q; a.Kc = c.Kc; a.Vc = c.Vc; a.offset = c.offset; a.freq = c.freq;
+  a.H = c.H; a.Tq = c.Tq; a.QB = c.QB; a.cap = c.cap; a.ring = c.ring;
+  launch_gemm(st, a, PRE_NONE);
+  AttnArgs at;
+  at.Q = c.q; at.Kc = c.Kc; at.Vc = c.Vc; at.offset = c.offset; at.H = c.H; at.Tq = c.Tq; at.QB = c.QB;
+  at.cap = c.cap; at.ring = c.ring; at.ctx = c.ctx; at.splits = c.splits; at.part = c.part; at.Y = c.ao; at.YF = DF;
+  const int BH = (c.M / c.Tq) * c.H;
+  attn_kernel<<<dim3(BH, c.QB, c.splits), 64, 0, st>>>(at);
+  if (c.splits > 1) attn_combine_kernel<<<dim3(BH, c.QB), 256, 0, st>>>(at);
+  a = mk_gemm(T.out, c.ao, DF, c.MT, c.M);
+  a.epi = EPI_RES; a.R = c.x_in; a.RF = DF; a.Y = c.x; a.YF = DF; a.ls = T.ls1;
+  launch_gemm(st, a, PRE_NONE);
+  launch_ln(st, c.x, 0, DF, c.h, DF, T.ln2_w, T.ln2_b, nullptr, nullptr, 0, DF, 1e-5f, c.MT, nullptr);
+  a = mk_gemm(T.ff1, c.h, DF, c.MT, c.M);
+  a.epi = EPI_STORE; a.act = ACT_GELU; a.Y = c.ff; a.YF = c.FF / 16;
+  launch_gemm(st, a, PRE_NONE);
+  a = mk_gemm(T.ff2, c.ff, c.FF / 16, c.MT, c.M);
+  a.epi = EPI_RES; a.R = c.x; a.RF = DF; a.Y = c.x_out; a.YF = DF; a.Ydstride = c.out_ds; a.par = c.par; a.ls = T.ls2;
+  launch_gemm(st, a, PRE_NONE);
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int ptts_abi_version(void) { return PTTS_ABI_VERSION; }
+extern "C" const char *ptts_last_error(void) { return g_err.c_str(); }
+
+static int seanet_check(const ptts_config &c) {
+  if (c.d_model % 64 || c.d_model / c.num_heads != 64) return fail(-4, "FlowLM head dim must be 64");
+  if (c.m_dim / c.m_heads != 64) return fail(-4, "Mimi head dim must be 64");
+  if (c.d_model > 1024 || c.m_dim > 1024 || c.flow_dim > 1024) return fail(-4, "LayerNorm width > 1024 unsupported");
+  if (c.ldim % 16 || c.flow_dim % 16 || c.ff_dim % 16 || c.m_ff % 16) return fail(-4, "dims must be multiples of 16");
+  if (c.upsample_stride != 16) return fail(-4, "upsample stride must be 16 (one row tile per frame)");
+  if ((c.n_filters / c.compress) % 16) return fail(-4, "n_filters/compress must be a multiple of 16");
+  return 0;
+}
+
+extern "C" int ptts_create(const ptts_config *cfg, const ptts_tensor *tensors, int32_t n, int32_t device,
+                           ptts_engine **out) {
+  if (!cfg || !tensors || !out) return fail(-1, "null argument");
+  CHK(seanet_check(*cfg));
+  HIPCHK(hipSetDevice(device));
+  ptts_engine *e = new ptts_engine();
+  e->cfg = *cfg;
+  e->device = device;
+  HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  g_alloc_stream = e->stream;
+  HIPCHK(hipEventCreate(&e->ev0));
+  HIPCHK(hipEventCreate(&e->ev1));
+  for (int i = 0; i < n; ++i) e->tmap[tensors[i].name] = &tensors[i];
+  const ptts_config &c = e->cfg;
+  const int D = c.d_model, FD = c.flow_dim;
+  std::string p = "flow_lm.";
+  CHK(copy_vec(e, p + "bos_emb", c.ldim, &e->bos));
+  CHK(make_freq(e, &e->freq_lm, c.max_period));
+  CHK(pack_lin(e, &e->in_linear, {{p + "input_linear.weight", "", D}}, c.ldim, 1));
+  e->lm.resize(c.num_layers);
+  for (int l = 0; l < c.num_layers; ++l)
+    CHK(pack_tr_layer(e, &e->lm[l], p + "transformer.layers." + std::to_string(l), D, c.ff_dim, false));
+  CHK(copy_vec(e, p + "out_norm.weight", D, &e->outnorm_w));
+  CHK(copy_vec(e, p + "out_norm.bias", D, &e->outnorm_b));
+  std::string f = p + "flow_net.";
+  // head = [cond_embed ; out_eos]: both read the out_norm output (flow_lm.py:129, mlp.py:209)
+  CHK(pack_lin(e, &e->head, {{f + "cond_embed.weight", f + "cond_embed.bias", FD}, {p + "out_eos.weight", p + "out_eos.bias", 1}}, D, 1));
+  {
+    std::vector<PackPart> parts;
+    for (int i = 0; i < c.flow_depth; ++i) {
+      std::string r = f + "res_blocks." + std::to_string(i) + ".adaLN_modulation.1.";
+      parts.push_back({r + "weight", r + "bias", 3 * FD});
+    }
+    parts.push_back({f + "final_layer.adaLN_modulation.1.weight", f + "final_layer.adaLN_modulation.1.bias", 2 * FD});
+    CHK(pack_lin(e, &e->adaln, parts, FD, 1));
+  }
+  CHK(pack_lin(e, &e->input_proj, {{f + "input_proj.weight", f + "input_proj.bias", FD}}, c.ldim, 1));
+  e->res.resize(c.flow_depth);
+  for (int i = 0; i < c.flow_depth; ++i) {
+    std::string r = f + "res_blocks." + std::to_string(i) + ".";
+    CHK(copy_vec(e, r + "in_ln.weight", FD, &e->res[i].ln_w));
+    CHK(copy_vec(e, r + "in_ln.bias", FD, &e->res[i].ln_b));
+    CHK(pack_lin(e, &e->res[i].l0, {{r + "mlp.0.weight", r + "mlp.0.bias", FD}}, FD, 1));
+    CHK(pack_lin(e, &e->res[i].l2, {{r + "mlp.2.weight", r + "mlp.2.bias", FD}}, FD, 1));
+  }
+  CHK(pack_lin(e, &e->fin, {{f + "final_layer.linear.weight", f + "final_layer.linear.bias", c.ldim}}, FD, 1));
+  for (int i = 0; i < 2; ++i) {
+    std::string t = f + "time_embed." + std::to_string(i) + ".";
+    CHK(copy_vec(e, t + "freqs", 128, &e->te_freqs[i]));
+    CHK(copy_vec(e, t + "mlp.3.alpha", FD, &e->te_alpha[i]));
+    CHK(pack_lin(e, &e->te_l0[i], {{t + "mlp.0.weight", t + "mlp.0.bias", FD}}, 256, 1));
+    CHK(pack_lin(e, &e->te_l2[i], {{t + "mlp.2.weight", t + "mlp.2.bias", FD}}, FD, 1));
+  }
+  CHK(dallocT(e, &e->te_scratch, (size_t)4 * 1024 * 16));
+  e->lm_bytes = e->in_linear.bytes() + e->head.bytes() + e->adaln.bytes() + e->input_proj.bytes() + e->fin.bytes();
+  for (auto &L : e->lm) e->lm_bytes += L.qkv.bytes() + L.out.bytes() + L.ff1.bytes() + L.ff2.bytes();
+  for (auto &R : e->res) e->lm_bytes += R.l0.bytes() + R.l2.bytes();
+
+  // ---- Mimi decode side
+  CHK(copy_vec(e, p + "emb_std", c.ldim, &e->emb_std));
+  CHK(copy_vec(e, p + "emb_mean", c.ldim, &e->emb_mean));
+  const int C = c.m_dim;
+  CHK(pack_lin(e, &e->quant, {{"mimi.quantizer.output_proj.weight", "", C}}, c.ldim, 1));
+  CHK(copy_vec(e, "mimi.upsample.convtr.convtr.weight", (int64_t)C * 2 * c.upsample_stride, &e->up_w));
+  CHK(make_freq(e, &e->freq_mimi, c.m_max_period));
+  e->mm.resize(c.m_layers);
+  for (int l = 0; l < c.m_layers; ++l)
+    CHK(pack_tr_layer(e, &e->mm[l], "mimi.decoder_transformer.transformer.layers." + std::to_string(l), C, c.m_ff, true));
+  e->ring = c.m_context > 0 ? (cdiv(c.m_context - 1, 16) + 1) * 16 : 0;
+  if (e->ring == 0) return fail(-4, "Mimi decoder transformer needs a finite context");
+  int mult = 8, idx = 1;
+  const int nf = c.n_filters;
+  CHK(pack_lin(e, &e->conv0, {{"mimi.decoder.model.0.conv.weight", "mimi.decoder.model.0.conv.bias", mult * nf}}, C, c.kernel_size));
+  if (C != mult * nf && false) return fail(-4, "unexpected seanet dims");
+  for (int i = 0; i < 3; ++i) {
+    const int cin = mult * nf, cout = cin / 2, s = c.ratios[i], hid = cout / c.compress;
+    std::string m = "mimi.decoder.model." + std::to_string(idx + 1);
+    CHK(pack_lin(e, &e->convtr[i], {{m + ".convtr.weight", m + ".convtr.bias", s * cout}}, cin, 2, 1, cout, s));
+    std::string r = "mimi.decoder.model." + std::to_string(idx + 2);
+    CHK(pack_lin(e, &e->res_a[i], {{r + ".block.1.conv.weight", r + ".block.1.conv.bias", hid}}, cout, c.res_kernel_size));
+    CHK(pack_lin(e, &e->res_b[i], {{r + ".block.3.conv.weight", r + ".block.3.conv.bias", cout}}, hid, 1));
+    idx += 3;
+    mult /= 2;
+  }
+  {
+    std::string m = "mimi.decoder.model." + std::to_string(idx + 1);
+    CHK(pack_lin(e, &e->conv_last, {{m + ".conv.weight", m + ".conv.bias", 1}}, nf, c.last_kernel_size));
+  }
+  e->mimi_bytes = e->quant.bytes() + e->conv0.bytes() + e->conv_last.bytes();
+  for (auto &L : e->mm) e->mimi_bytes += L.qkv.bytes() + L.out.bytes() + L.ff1.bytes() + L.ff2.bytes();
+  for (int i = 0; i < 3; ++i) e->mimi_bytes += e->convtr[i].bytes() + e->res_a[i].bytes() + e->res_b[i].bytes();
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->tmap.clear();
+  *out = e;
+  return 0;
+}
+
+extern "C" void ptts_destroy(ptts_engine *e) {
+  if (!e) return;
+  hipSetDevice(e->device);
+  hipDeviceSynchronize();
+  for (void *p : e->allocs) hipFree(p);
+  if (e->ev0) hipEventDestroy(e->ev0);
+  if (e->ev1) hipEventDestroy(e->ev1);
+  if (e->stream) hipStreamDestroy(e->stream);
+  delete e;
+}
+
+static hipStream_t S(ptts_engine *e, void *stream) { return stream ? (hipStream_t)stream : e->stream; }
+
+// time-embedding constant for a given LSD schedule (reference mlp.py:203-206): computed once on device
+static int prepare_lsd(ptts_engine *e, int steps) {
+  if (e->tcomb.count(steps)) return 0;
+  if (steps < 1 || steps > 64) return fail(-1, "lsd_decode_steps out of range");
+  const int FD = e->cfg.flow_dim;
+  float *tab;
+  g_alloc_stream = e->stream;
+  CHK(dallocT(e, &tab, (size_t)steps * FD));
+  hipStream_t st = e->stream;
+  float *efm = e->te_scratch, *h = efm + 16 * 1024, *h0 = h + 16 * 1024, *h1 = h0 + 16 * 1024;
+  for (int i = 0; i < steps; ++i) {
+    const float tv[2] = {(float)((double)i / steps), (float)((double)(i + 1) / steps)};
+    float *ho[2] = {h0, h1};
+    for (int k = 0; k < 2; ++k) {
+      timestep_embed_kernel<<<1, 256, 0, st>>>(e->te_freqs[k], tv[k], efm, 128);
+      GemmArgs a = mk_gemm(e->te_l0[k], efm, 16, 1, 1);
+      a.act = ACT_SILU; a.Y = h; a.YF = FD / 16;
+      launch_gemm(st, a, PRE_NONE);
+      a = mk_gemm(e->te_l2[k], h, FD / 16, 1, 1);
+      a.Y = ho[k]; a.YF = FD / 16;
+      launch_gemm(st, a, PRE_NONE);
+    }
+    tcomb_kernel<<<1, 64, 0, st>>>(h0, h1, e->te_alpha[0], e->te_alpha[1], tab + (size_t)i * FD, FD);
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  e->tcomb[steps] = tab;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FlowLM state
+static int alloc_scratch(ptts_engine *e, Scratch *s, int B, int Tq, int D, int H, int FF, int cap) {
+  const int M = B * Tq;
+  s->MT = cdiv(M, 16);
+  s->QB = cdiv(Tq, 16);
+  const size_t rowt = (size_t)s->MT * 256;
+  CHK(dallocT(nullptr, &s->x, rowt * (D / 16)));
+  CHK(dallocT(nullptr, &s->h, rowt * (D / 16)));
+  CHK(dallocT(nullptr, &s->ao, rowt * (D / 16)));
+  CHK(dallocT(nullptr, &s->ff, rowt * (FF / 16)));
+  CHK(dallocT(nullptr, &s->q, (size_t)B * H * s->QB * 4 * 256));
+  s->splits_cap = attn_splits(B * H * s->QB, cdiv(cap, 16));
+  CHK(dallocT(nullptr, &s->part, (size_t)B * H * s->QB * s->splits_cap * 16 * ATT_PSTRIDE));
+  return 0;
+}
+static void free_scratch(Scratch *s) {
+  hipFree(s->x); hipFree(s->h); hipFree(s->ao); hipFree(s->ff); hipFree(s->q); hipFree(s->part);
+  *s = Scratch();
+}
+
+extern "C" int ptts_lm_state_create(ptts_engine *e, int32_t B, int32_t t_cap, ptts_lm_state **out) {
+  if (!e || B < 1 || t_cap < 1) return fail(-1, "bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  const ptts_config &c = e->cfg;
+  g_alloc_stream = e->stream;
+  ptts_lm_state *s = new ptts_lm_state();
+  s->e = e;
+  s->B = B;
+  s->cap = cdiv(t_cap, 16) * 16;
+  s->MT = cdiv(B, 16);
+  CHK(dallocT(nullptr, &s->kv, (size_t)c.num_layers * 2 * s->kv_plane()));
+  CHK(dallocT(nullptr, &s->offset, B));
+  s->h_off.assign(B, 0);
+  CHK(alloc_scratch(e, &s->dec, B, 1, c.d_model, c.num_heads, c.ff_dim, s->cap));
+  const size_t rt = (size_t)s->MT * 256;
+  const int FD = c.flow_dim;
+  CHK(dallocT(nullptr, &s->xlat, rt * (c.ldim / 16)));
+  CHK(dallocT(nullptr, &s->latfm, rt * (c.ldim / 16)));
+  CHK(dallocT(nullptr, &s->c, rt * (c.d_model / 16)));
+  CHK(dallocT(nullptr, &s->ce, rt * (FD / 16)));
+  CHK(dallocT(nullptr, &s->mod, rt * e->adaln.NT));
+  CHK(dallocT(nullptr, &s->fx, rt * (FD / 16)));
+  CHK(dallocT(nullptr, &s->fh, rt * (FD / 16)));
+  CHK(dallocT(nullptr, &s->f1, rt * (FD / 16)));
+  CHK(dallocT(nullptr, &s->lat, (size_t)B * c.ldim));
+  CHK(dallocT(nullptr, &s->lat_prev, (size_t)B * c.ldim));
+  CHK(dallocT(nullptr, &s->eos_logit, B));
+  CHK(dallocT(nullptr, &s->is_eos, B));
+  fill_kernel<<<cdiv(B * c.ldim, 256), 256, 0, e->stream>>>(s->lat_prev, (long)B * c.ldim, NAN);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  *out = s;
+  return 0;
+}
+
+extern "C" void ptts_lm_state_destroy(ptts_lm_state *s) {
+  if (!s) return;
+  hipSetDevice(s->e->device);
+  hipDeviceSynchronize();
+  hipFree(s->kv); hipFree(s->offset);
+  free_scratch(&s->dec);
+  if (s->pre.x) free_scratch(&s->pre);
+  hipFree(s->xlat); hipFree(s->latfm); hipFree(s->c); hipFree(s->ce); hipFree(s->mod); hipFree(s->fx);
+  hipFree(s->fh); hipFree(s->f1); hipFree(s->lat); hipFree(s->lat_prev); hipFree(s->eos_logit); hipFree(s->is_eos);
+  delete s;
+}
+
+extern "C" int ptts_lm_state_reset(ptts_lm_state *s, void *stream) {
+  hipStream_t st = S(s->e, stream);
+  set_int_kernel<<<cdiv(s->B, 256), 256, 0, st>>>(s->offset, s->B, 0);
+  fill_kernel<<<cdiv(s->B * s->e->cfg.ldim, 256), 256, 0, st>>>(s->lat_prev, (long)s->B * s->e->cfg.ldim, NAN);
+  std::fill(s->h_off.begin(), s->h_off.end(), 0);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int ptts_lm_state_import(ptts_lm_state *s, int32_t layer, const float *d_cache, int32_t src_batch,
+                                    int32_t t, void *stream) {
+  const ptts_config &c = s->e->cfg;
+  if (layer < 0 || layer >= c.num_layers) return fail(-1, "layer out of range");
+  if (t > s->cap) return fail(-5, "import: t exceeds cache capacity");
+  if (src_batch != 1 && src_batch != s->B) return fail(-1, "import: src_batch must be 1 or B");
+  hipStream_t st = S(s->e, stream);
+  if (t > 0) {
+    long total = 2L * s->B * t * c.num_heads * 16;
+    kv_import_kernel<<<cdiv(total, 256), 256, 0, st>>>(d_cache, s->K(layer), s->V(layer), s->B, src_batch, t,
+                                                        c.num_heads, s->cap);
+  }
+  set_int_kernel<<<cdiv(s->B, 256), 256, 0, st>>>(s->offset, s->B, t);
+  std::fill(s->h_off.begin(), s->h_off.end(), t);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int ptts_lm_state_export(ptts_lm_state *s, int32_t layer, float *d_cache, int32_t t, void *stream) {
+  const ptts_config &c = s->e->cfg;
+  if (layer < 0 || layer >= c.num_layers) return fail(-1, "layer out of range");
+  if (t > s->cap) return fail(-5, "export: t exceeds cache capacity");
+  hipStream_t st = S(s->e, stream);
+  long total = 2L * s->B * t * c.num_heads * 16;
+  if (total) kv_export_kernel<<<cdiv(total, 256), 256, 0, st>>>(d_cache, s->K(layer), s->V(layer), s->B, t, c.num_heads, s->cap);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int ptts_lm_state_copy(ptts_lm_state *dst, const ptts_lm_state *src, void *stream) {
+  if (dst->e != src->e) return fail(-1, "states belong to different engines");
+  if (src->B != 1 && src->B != dst->B) return fail(-1, "copy: src batch must be 1 or equal");
+  const ptts_config &c = dst->e->cfg;
+  hipStream_t st = S(dst->e, stream);
+  const int T = *std::max_element(src->h_off.begin(), src->h_off.end());
+  if (T > dst->cap) return fail(-5, "copy: destination capacity too small");
+  if (dst->cap == src->cap) {
+    long per_row = (long)c.num_heads * dst->cap * 64;
+    long total = (long)c.num_layers * 2 * dst->B * (per_row / 4);
+    kv_copy_kernel<<<cdiv(total, 256), 256, 0, st>>>(dst->kv, src->kv, per_row, dst->B, src->B, c.num_layers * 2);
+  } else {
+    // different capacities: go plane by plane through the reference layout-free row copy
+    for (int pl = 0; pl < c.num_layers * 2; ++pl)
+      for (int b = 0; b < dst->B; ++b)
+        for (int h = 0; h < c.num_heads; ++h) {
+          const int sb = src->B == 1 ? 0 : b;
+          const float *sp = src->kv + (((size_t)pl * src->B + sb) * c.num_heads + h) * src->cap * 64;
+          float *dp = dst->kv + (((size_t)pl * dst->B + b) * c.num_heads + h) * dst->cap * 64;
+          if (T) HIPCHK(hipMemcpyAsync(dp, sp, (size_t)T * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+  }
+  for (int b = 0; b < dst->B; ++b) dst->h_off[b] = src->h_off[src->B == 1 ? 0 : b];
+  HIPCHK(hipMemcpyAsync(dst->offset, dst->h_off.data(), dst->B * sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));  // h_off.data() is pageable host memory
+  return 0;
+}
+
+extern "C" int ptts_lm_state_offsets(ptts_lm_state *s, int32_t *h, void *stream) {
+  hipStream_t st = S(s->e, stream);
+  HIPCHK(hipMemcpyAsync(h, s->offset, s->B * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+extern "C" const float *ptts_lm_latent_ptr(ptts_lm_state *s) { return s->lat_prev; }
+
+static void lm_layers(hipStream_t st, ptts_engine *e, ptts_lm_state *s, Scratch &sc, int M, int Tq) {
+  const ptts_config &c = e->cfg;
+  for (int l = 0; l < c.num_layers; ++l) {
+    TrCtx t;
+    t.D = c.d_model; t.H = c.num_heads; t.FF = c.ff_dim; t.MT = sc.MT; t.M = M; t.Tq = Tq; t.QB = sc.QB;
+    t.cap = s->cap; t.ring = 0; t.ctx = 0;
+    t.splits = std::min(sc.splits_cap, attn_splits(s->B * c.num_heads * sc.QB, cdiv(s->cap, 16)));
+    t.x_in = sc.x; t.x = sc.x; t.x_out = sc.x; t.out_ds = 0; t.par = nullptr;
+    t.h = sc.h; t.ao = sc.ao; t.ff = sc.ff; t.q = sc.q; t.part = sc.part;
+    t.Kc = s->K(l); t.Vc = s->V(l); t.offset = s->offset; t.freq = e->freq_lm;
+    run_tr_layer(st, e->lm[l], t);
+  }
+}
+
+extern "C" int ptts_lm_prefill(ptts_engine *e, ptts_lm_state *s, const float *d_emb, int32_t T, void *stream) {
+  if (T < 1) return 0;
+  HIPCHK(hipSetDevice(e->device));
+  const ptts_config &c = e->cfg;
+  for (int b = 0; b < s->B; ++b)
+    if (s->h_off[b] + T > s->cap) return fail(-5, "prefill: KV cache capacity exceeded");
+  hipStream_t st = S(e, stream);
+  const int M = s->B * T;
+  if (!s->pre.x || s->pre.MT < cdiv(M, 16) || s->pre.QB != cdiv(T, 16)) {
+    HIPCHK(hipStreamSynchronize(st));
+    if (s->pre.x) free_scratch(&s->pre);
+    g_alloc_stream = st;
+    CHK(alloc_scratch(e, &s->pre, s->B, T, c.d_model, c.num_heads, c.ff_dim, s->cap));
+  }
+  Scratch &sc = s->pre;
+  const int MT = cdiv(M, 16);
+  sc.MT = MT;
+  long n4 = (long)MT * (c.d_model / 16) * 64;
+  to_fm_kernel<<<cdiv(n4, 256), 256, 0, st>>>(d_emb, sc.x, M, c.d_model, MT);
+  lm_layers(st, e, s, sc, M, T);
+  add_int_kernel<<<cdiv(s->B, 256), 256, 0, st>>>(s->offset, s->B, T);
+  for (auto &o : s->h_off) o += T;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, const float *d_latent_in,
+                           const float *d_noise, int lsd_steps, float eos_thr, float *d_latent_out,
+                           float *d_eos_logit, uint8_t *d_is_eos) {
+  const ptts_config &c = e->cfg;
+  const int B = s->B, MT = s->MT, D = c.d_model, FD = c.flow_dim, DF = D / 16, FDF = FD / 16, LF = c.ldim / 16;
+  Scratch &sc = s->dec;
+  const float *tcomb = e->tcomb[lsd_steps];
+  prep_lm_kernel<<<cdiv(MT * LF * 64, 256), 256, 0, st>>>(d_latent_in ? d_latent_in : s->lat_prev, e->bos, d_noise,
+                                                           s->xlat, s->lat, s->latfm, B, c.ldim, MT);
+  GemmArgs a = mk_gemm(e->in_linear, s->xlat, LF, MT, B);
+  a.Y = sc.x; a.YF = DF;
+  launch_gemm(st, a, PRE_NONE);
+  lm_layers(st, e, s, sc, B, 1);
+  launch_ln(st, sc.x, 0, DF, s->c, DF, e->outnorm_w, e->outnorm_b, nullptr, nullptr, 0, DF, 1e-5f, MT, nullptr);
+  a = mk_gemm(e->head, s->c, DF, MT, B);
+  a.epi = EPI_HEAD; a.Y = s->ce; a.YF = FDF; a.head_nt = FDF; a.eos_thr = eos_thr;
+  a.eos_logit = s->eos_logit; a.is_eos = s->is_eos;
+  launch_gemm(st, a, PRE_NONE);
+  const int AF = e->adaln.NT;
+  for (int i = 0; i < lsd_steps; ++i) {
+    // all AdaLN modulations of the step in one GEMM on silu(t_emb + cond)  (mlp.py:107,127,210)
+    a = mk_gemm(e->adaln, s->ce, FDF, MT, B);
+    a.prevec = tcomb + (size_t)i * FD; a.Y = s->mod; a.YF = AF;
+    launch_gemm(st, a, PRE_ADDSILU);
+    a = mk_gemm(e->input_proj, s->latfm, LF, MT, B);
+    a.Y = s->fx; a.YF = FDF;
+    launch_gemm(st, a, PRE_NONE);
+    for (int r = 0; r < c.flow_depth; ++r) {
+      const float *shift = s->mod + (size_t)(r * 3 * FDF) * 256;
+      const float *scale = shift + (size_t)FDF * 256;
+      const float *gate = scale + (size_t)FDF * 256;
+      launch_ln(st, s->fx, 0, FDF, s->fh, FDF, e->res[r].ln_w, e->res[r].ln_b, shift, scale, AF, FDF, 1e-6f, MT, nullptr);
+      a = mk_gemm(e->res[r].l0, s->fh, FDF, MT, B);
+      a.act = ACT_SILU; a.Y = s->f1; a.YF = FDF;
+      launch_gemm(st, a, PRE_NONE);
+      a = mk_gemm(e->res[r].l2, s->f1, FDF, MT, B);
+      a.epi = EPI_GATE; a.R = s->fx; a.RF = FDF; a.G = gate; a.GF = AF; a.Y = s->fx; a.YF = FDF;
+      launch_gemm(st, a, PRE_NONE);
+    }
+    const float *shift = s->mod + (size_t)(c.flow_depth * 3 * FDF) * 256;
+    const float *scale = shift + (size_t)FDF * 256;
+    launch_ln(st, s->fx, 0, FDF, s->fh, FDF, nullptr, nullptr, shift, scale, AF, FDF, 1e-6f, MT, nullptr);
+    a = mk_gemm(e->fin, s->fh, FDF, MT, B);
+    a.epi = EPI_LATENT; a.lat = s->lat; a.ldim = c.ldim; a.inv_steps = 1.0f / (float)lsd_steps; a.Y = s->latfm; a.YF = LF;
+    launch_gemm(st, a, PRE_NONE);
+  }
+  add_int_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->offset, B, 1);
+  hipMemcpyAsync(s->lat_prev, s->lat, (size_t)B * c.ldim * sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (d_latent_out) hipMemcpyAsync(d_latent_out, s->lat, (size_t)B * c.ldim * sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (d_eos_logit) hipMemcpyAsync(d_eos_logit, s->eos_logit, B * sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (d_is_eos) hipMemcpyAsync(d_is_eos, s->is_eos, B, hipMemcpyDeviceToDevice, st);
+  return 0;
+}
+
+extern "C" int ptts_lm_decode_step(ptts_engine *e, ptts_lm_state *s, const float *d_latent_in, const float *d_noise,
+                                   int32_t lsd_steps, float eos_threshold, float *d_latent_out, float *d_eos_logit,
+                                   uint8_t *d_is_eos, void *stream) {
+  HIPCHK(hipSetDevice(e->device));
+  CHK(prepare_lsd(e, lsd_steps));
+  for (int b = 0; b < s->B; ++b)
+    if (s->h_off[b] + 1 > s->cap) return fail(-5, "decode: KV cache capacity exceeded");
+  CHK(lm_step_enqueue(S(e, stream), e, s, d_latent_in, d_noise, lsd_steps, eos_threshold, d_latent_out, d_eos_logit, d_is_eos));
+  for (auto &o : s->h_off) o += 1;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mimi
+extern "C" int ptts_mimi_state_create(ptts_engine *e, int32_t B, ptts_mimi_state **out) {
+  if (!e || B < 1) return fail(-1, "bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  const ptts_config &c = e->cfg;
+  g_alloc_stream = e->stream;
+  ptts_mimi_state *s = new ptts_mimi_state();
+  s->e = e;
+  s->B = B;
+  s->MTb = cdiv(B, 16);
+  s->MT16 = B;  // one 16-row tile per sequence
+  const int C = c.m_dim, CF = C / 16;
+  CHK(dallocT(nullptr, &s->frame, 1));
+  CHK(dallocT(nullptr, &s->offset, B));
+  CHK(dallocT(nullptr, &s->kv, (size_t)c.m_layers * 2 * s->kv_plane()));
+  CHK(dallocT(nullptr, &s->zl, (size_t)s->MTb * 256 * (c.ldim / 16)));
+  s->zq_stride = (long)s->MTb * 256 * CF;
+  CHK(dallocT(nullptr, &s->zq, (size_t)2 * s->zq_stride));
+  const size_t r16 = (size_t)s->MT16 * 256;
+  CHK(dallocT(nullptr, &s->u0, r16 * CF));
+  CHK(dallocT(nullptr, &s->u, r16 * CF));
+  CHK(dallocT(nullptr, &s->h, r16 * CF));
+  CHK(dallocT(nullptr, &s->ao, r16 * CF));
+  CHK(dallocT(nullptr, &s->ff, r16 * (c.m_ff / 16)));
+  CHK(dallocT(nullptr, &s->q, (size_t)B * c.m_heads * 4 * 256));
+  s->splits = attn_splits(B * c.m_heads, e->ring / 16);
+  CHK(dallocT(nullptr, &s->part, (size_t)B * c.m_heads * s->splits * 16 * ATT_PSTRIDE));
+  s->tr_stride = (long)r16 * CF;
+  CHK(dallocT(nullptr, &s->tr_out, (size_t)2 * s->tr_stride));
+  int mult = 8, rows = 16;
+  s->rows[0] = rows;
+  s->a0_stride = (long)r16 * (mult * c.n_filters / 16);
+  CHK(dallocT(nullptr, &s->a0, (size_t)2 * s->a0_stride));
+  for (int i = 0; i < 3; ++i) {
+    const int cout = mult * c.n_filters / 2, hid = cout / c.compress;
+    rows *= c.ratios[i];
+    s->rows[i + 1] = rows;
+    const size_t rt = (size_t)B * (rows / 16) * 256;
+    s->c_stride[i] = (long)rt * (cout / 16);
+    s->s_stride[i] = s->c_stride[i];
+    CHK(dallocT(nullptr, &s->cbuf[i], (size_t)2 * s->c_stride[i]));
+    CHK(dallocT(nullptr, &s->sbuf[i], (size_t)2 * s->s_stride[i]));
+    CHK(dallocT(nullptr, &s->rbuf[i], rt * (hid / 16)));
+    mult /= 2;
+  }
+  CHK(dallocT(nullptr, &s->pcm_dbg, (size_t)B * rows));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  *out = s;
+  return 0;
+}
+
+extern "C" void ptts_mimi_state_destroy(ptts_mimi_state *s) {
+  if (!s) return;
+  hipSetDevice(s->e->device);
+  hipDeviceSynchronize();
+  hipFree(s->frame); hipFree(s->offset); hipFree(s->kv); hipFree(s->zl); hipFree(s->zq); hipFree(s->u0);
+  hipFree(s->u); hipFree(s->h); hipFree(s->ao); hipFree(s->ff); hipFree(s->q); hipFree(s->part);
+  hipFree(s->tr_out); hipFree(s->a0); hipFree(s->pcm_dbg);
+  for (int i = 0; i < 3; ++i) { hipFree(s->cbuf[i]); hipFree(s->rbuf[i]); hipFree(s->sbuf[i]); }
+  delete s;
+}
+
+extern "C" int ptts_mimi_state_reset(ptts_mimi_state *s, void *stream) {
+  hipStream_t st = S(s->e, stream);
+  // zero-initialised carries == `previous` / `partial` zeros of init_state (conv.py:84-91,145-149)
+  HIPCHK(hipMemsetAsync(s->frame, 0, sizeof(int), st));
+  HIPCHK(hipMemsetAsync(s->offset, 0, s->B * sizeof(int), st));
+  HIPCHK(hipMemsetAsync(s->zq, 0, (size_t)2 * s->zq_stride * 4, st));
+  HIPCHK(hipMemsetAsync(s->tr_out, 0, (size_t)2 * s->tr_stride * 4, st));
+  HIPCHK(hipMemsetAsync(s->a0, 0, (size_t)2 * s->a0_stride * 4, st));
+  for (int i = 0; i < 3; ++i) {
+    HIPCHK(hipMemsetAsync(s->cbuf[i], 0, (size_t)2 * s->c_stride[i] * 4, st));
+    HIPCHK(hipMemsetAsync(s->sbuf[i], 0, (size_t)2 * s->s_stride[i] * 4, st));
+  }
+  HIPCHK(hipMemsetAsync(s->kv, 0, (size_t)s->e->cfg.m_layers * 2 * s->kv_plane() * 4, st));
+  s->h_frame = 0;
+  return 0;
+}
+
+static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, const float *d_latent, float *d_pcm) {
+  const ptts_config &c = e->cfg;
+  const int B = s->B, C = c.m_dim, CF = C / 16, LF = c.ldim / 16, st16 = c.upsample_stride;
+  prep_mimi_kernel<<<cdiv(s->MTb * LF * 64, 256), 256, 0, st>>>(d_latent, e->emb_std, e->emb_mean, s->zl, B, c.ldim, s->MTb);
+  GemmArgs a = mk_gemm(e->quant, s->zl, LF, s->MTb, B);
+  a.Y = s->zq; a.Ydstride = s->zq_stride; a.YF = CF; a.par = s->frame;
+  launch_gemm(st, a, PRE_NONE);
+  long tot = (long)B * st16 * (C / 4);
+  upsample_kernel<<<cdiv(tot, 256), 256, 0, st>>>(s->zq, s->zq_stride, s->frame, e->up_w, s->u0, B, C, st16);
+  const int M16 = B * st16;
+  for (int l = 0; l < c.m_layers; ++l) {
+    TrCtx t;
+    t.D = C; t.H = c.m_heads; t.FF = c.m_ff; t.MT = s->MT16; t.M = M16; t.Tq = st16; t.QB = 1;
+    t.cap = e->ring; t.ring = e->ring; t.ctx = c.m_context; t.splits = s->splits;
+    t.x_in = l == 0 ? s->u0 : s->u; t.x = s->u;
+    const bool last = l == c.m_layers - 1;
+    t.x_out = last ? s->tr_out : s->u; t.out_ds = last ? s->tr_stride : 0; t.par = last ? s->frame : nullptr;
+    t.h = s->h; t.ao = s->ao; t.ff = s->ff; t.q = s->q; t.part = s->part;
+    t.Kc = s->K(l); t.Vc = s->V(l); t.offset = s->offset; t.freq = e->freq_mimi;
+    run_tr_layer(st, e->mm[l], t);
+  }
+  // SEANet decoder (seanet.py:141-180) as implicit GEMMs over (sequence, time) rows
+  int mult = 8;
+  a = mk_gemm(e->conv0, s->tr_out, CF, s->MT16, M16);
+  a.Xdstride = s->tr_stride; a.T = s->rows[0]; a.par = s->frame;
+  a.Y = s->a0; a.Ydstride = s->a0_stride; a.YF = mult * c.n_filters / 16;
+  launch_gemm(st, a, PRE_NONE);
+  const float *xin = s->a0;
+  long xds = s->a0_stride;
+  for (int i = 0; i < 3; ++i) {
+    const int cin = mult * c.n_filters, cout = cin / 2, hid = cout / c.compress;
+    const int Tin = s->rows[i], Tout = s->rows[i + 1];
+    const int MTin = B * Tin / 16, MTout = B * Tout / 16;
+    a = mk_gemm(e->convtr[i], xin, cin / 16, MTin, B * Tin);
+    a.Xdstride = xds; a.T = Tin; a.par = s->frame;
+    a.epi = EPI_CONVTR; a.cout = cout; a.stride = c.ratios[i];
+    a.Y = s->cbuf[i]; a.Ydstride = s->c_stride[i]; a.YF = cout / 16;
+    launch_gemm(st, a, PRE_ELU);
+    a = mk_gemm(e->res_a[i], s->cbuf[i], cout / 16, MTout, B * Tout);
+    a.Xdstride = s->c_stride[i]; a.T = Tout; a.par = s->frame;
+    a.Y = s->rbuf[i]; a.YF = hid / 16;
+    launch_gemm(st, a, PRE_ELU);
+    a = mk_gemm(e->res_b[i], s->rbuf[i], hid / 16, MTout, B * Tout);
+    a.T = Tout; a.par = s->frame;
+    a.epi = EPI_RES; a.R = s->cbuf[i]; a.Rdstride = s->c_stride[i]; a.RF = cout / 16;
+    a.Y = s->sbuf[i]; a.Ydstride = s->s_stride[i]; a.YF = cout / 16;
+    launch_gemm(st, a, PRE_ELU);
+    xin = s->sbuf[i];
+    xds = s->s_stride[i];
+    mult /= 2;
+  }
+  const int Tl = s->rows[3];
+  a = mk_gemm(e->conv_last, xin, c.n_filters / 16, B * Tl / 16, B * Tl);
+  a.Xdstride = xds; a.T = Tl; a.par = s->frame;
+  a.epi = EPI_PCM; a.pcm = d_pcm ? d_pcm : s->pcm_dbg;
+  launch_gemm(st, a, PRE_ELU);
+  add_int_kernel<<<1, 64, 0, st>>>(s->frame, 1, 1);
+  add_int_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->offset, B, st16);
+  return 0;
+}
+
+extern "C" int ptts_mimi_decode(ptts_engine *e, ptts_mimi_state *s, const float *d_latent, float *d_pcm, void *stream) {
+  HIPCHK(hipSetDevice(e->device));
+  if (!d_latent) return fail(-1, "null latent");
+  CHK(mimi_enqueue(S(e, stream), e, s, d_latent, d_pcm));
+  s->h_frame += 1;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// hipGraph capture
+template <typename F>
+static int capture(ptts_engine *e, ptts_graph *g, F &&body) {
+  HIPCHK(hipStreamCreateWithFlags(&g->cap_stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamBeginCapture(g->cap_stream, hipStreamCaptureModeThreadLocal));
+  int r = body(g->cap_stream);
+  hipError_t er = hipStreamEndCapture(g->cap_stream, &g->graph);
+  if (r < 0) return r;
+  HIPCHK(er);
+  HIPCHK(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
+  return 0;
+}
+
+extern "C" int ptts_graph_capture_lm_step(ptts_engine *e, ptts_lm_state *s, const float *d_noise, int32_t lsd_steps,
+                                          float eos_threshold, float *d_latent_out, float *d_eos_logit,
+                                          uint8_t *d_is_eos, ptts_graph **out) {
+  HIPCHK(hipSetDevice(e->device));
+  CHK(prepare_lsd(e, lsd_steps));
+  ptts_graph *g = new ptts_graph();
+  g->lm = s;
+  CHK(capture(e, g, [&](hipStream_t st) {
+    return lm_step_enqueue(st, e, s, nullptr, d_noise, lsd_steps, eos_threshold, d_latent_out, d_eos_logit, d_is_eos);
+  }));
+  *out = g;
+  return 0;
+}
+
+extern "C" int ptts_graph_capture_mimi(ptts_engine *e, ptts_mimi_state *s, const float *d_latent, float *d_pcm,
+                                       ptts_graph **out) {
+  HIPCHK(hipSetDevice(e->device));
+  ptts_graph *g = new ptts_graph();
+  g->mimi = s;
+  CHK(capture(e, g, [&](hipStream_t st) { return mimi_enqueue(st, e, s, d_latent, d_pcm); }));
+  *out = g;
+  return 0;
+}
+
+extern "C" int ptts_graph_launch(ptts_graph *g, void *stream) {
+  ptts_engine *e = g->lm ? g->lm->e : g->mimi->e;
+  if (g->lm) {
+    for (int b = 0; b < g->lm->B; ++b)
+      if (g->lm->h_off[b] + 1 > g->lm->cap) return fail(-5, "decode: KV cache capacity exceeded");
+  }
+  HIPCHK(hipGraphLaunch(g->exec, S(e, stream)));
+  if (g->lm) for (auto &o : g->lm->h_off) o += 1;
+  if (g->mimi) g->mimi->h_frame += 1;
+  return 0;
+}
+
+extern "C" void ptts_graph_destroy(ptts_graph *g) {
+  if (!g) return;
+  if (g->exec) hipGraphExecDestroy(g->exec);
+  if (g->graph) hipGraphDestroy(g->graph);
+  if (g->cap_stream) hipStreamDestroy(g->cap_stream);
+  delete g;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int ptts_sync(ptts_engine *e, void *stream) {
+  HIPCHK(hipStreamSynchronize(S(e, stream)));
+  return 0;
+}
+extern "C" void *ptts_engine_stream(ptts_engine *e) { return (void *)e->stream; }
+extern "C" int ptts_timer_start(ptts_engine *e, void *stream) {
+  HIPCHK(hipEventRecord(e->ev0, S(e, stream)));
+  return 0;
+}
+extern "C" int ptts_timer_stop_ms(ptts_engine *e, void *stream, float *ms) {
+  HIPCHK(hipEventRecord(e->ev1, S(e, stream)));
+  HIPCHK(hipEventSynchronize(e->ev1));
+  HIPCHK(hipEventElapsedTime(ms, e->ev0, e->ev1));
+  return 0;
+}
+extern "C" int64_t ptts_lm_weight_bytes(ptts_engine *e) { return e->lm_bytes; }
+extern "C" int64_t ptts_mimi_weight_bytes(ptts_engine *e) { return e->mimi_bytes; }
+
+extern "C" int64_t ptts_debug_read(ptts_engine *e, void *state, int32_t is_mimi, const char *name, float *d_out,
+                                   int64_t capacity, int32_t *rows, int32_t *cols, void *stream) {
+  hipStream_t st = S(e, stream);
+  const ptts_config &c = e->cfg;
+  const float *src = nullptr;
+  int M = 0, K = 0, F = 0;
+  std::string n(name);
+  if (!is_mimi) {
+    ptts_lm_state *s = (ptts_lm_state *)state;
+    if (n == "x") { src = s->dec.x; M = s->B; K = c.d_model; }
+    else if (n == "cond") { src = s->c; M = s->B; K = c.d_model; }
+    else if (n == "ce") { src = s->ce; M = s->B; K = c.flow_dim; }
+    else if (n == "fx") { src = s->fx; M = s->B; K = c.flow_dim; }
+    else if (n == "prefill_x") { src = s->pre.x; M = s->pre.MT * 16; K = c.d_model; }
+    else return fail(-1, "unknown buffer " + n);
+    F = K / 16;
+  } else {
+    ptts_mimi_state *s = (ptts_mimi_state *)state;
+    const int par = (s->h_frame - 1) & 1;  // parity of the frame decoded last
+    const int B = s->B;
+    if (n == "upsample") { src = s->u0; M = B * 16; K = c.m_dim; }
+    else if (n == "dec_tr") { src = s->tr_out + par * s->tr_stride; M = B * 16; K = c.m_dim; }
+    else if (n == "seanet0") { src = s->a0 + par * s->a0_stride; M = B * 16; K = 8 * c.n_filters; }
+    else if (n == "seanet11") {
+      M = B; K = s->rows[3];
+      if ((int64_t)M * K > capacity) return fail(-1, "capacity");
+      if (hipMemcpyAsync(d_out, s->pcm_dbg, (size_t)M * K * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(-2, "memcpy");
+      *rows = M; *cols = K;
+      return (int64_t)M * K;
+    } else {
+      int idx = atoi(n.c_str() + 6);
+      if (n.compare(0, 6, "seanet") != 0 || idx < 2 || idx > 9) return fail(-1, "unknown buffer " + n);
+      int stage = (idx - 2) / 3;
+      bool is_res = (idx - 2) % 3 == 1;
+      if ((idx - 2) % 3 == 2) return fail(-1, "unknown buffer " + n);
+      int mult = 8 >> stage;
+      K = mult * c.n_filters / 2;
+      M = B * s->rows[stage + 1];
+      src = is_res ? s->sbuf[stage] + par * s->s_stride[stage] : s->cbuf[stage] + par * s->c_stride[stage];
+    }
+    F = K / 16;
+  }
+  if ((int64_t)M * K > capacity) return fail(-1, "debug_read: capacity too small");
+  long n4 = (long)M * (K / 4);
+  from_fm_kernel<<<cdiv(n4, 256), 256, 0, st>>>(src, d_out, M, K, F, 0);
+  *rows = M;
+  *cols = K;
+  return (int64_t)M * K;
+}

@@ -1,0 +1,781 @@
+// Device kernels of the Pocket-TTS decode hot path for gfx950 (MI355X, CDNA4).
+//
+// Data layout ("FM" = MFMA-fragment-major).  Every activation matrix X[M][K] (rows = batch rows or
+// (sequence, time) positions, K = channels, both padded to multiples of 16) is stored so that the
+// 1 KiB a wave loads with one `global_load_dwordx4` is exactly one operand fragment of
+// v_mfma_f32_16x16x4_f32:
+//     element (m, k)  ->  float index  (((m/16)*F + k/16)*64 + 16*((k%16)/4) + m%16)*4 + k%4,   F = K/16
+// i.e. lane l of the wave holds X[16*mt + (l&15)][16*kf + 4*(l>>4) + j], j = 0..3, and MFMA step j
+// consumes element j of every lane.  Weights W[N][K] are packed once at load time into the same
+// order with n in place of m, so the weight stream is a sequence of fully coalesced 1 KiB loads that go
+// straight to VGPRs (no LDS round trip for an operand that is read exactly once).  The 16x16 fp32
+// accumulator of an (n-tile, m-tile) pair is, lane for lane, fragment kf = n-tile of the next GEMM's
+// input, so producers store it with one 1 KiB coalesced store and no shuffles.
+//
+// All arithmetic is fp32 (the reference runs fp32: english.yaml:9,27); the fp32-input MFMA is an exact
+// k-ordered fmaf chain, so results differ from the reference only by summation order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { PRE_NONE = 0, PRE_ELU = 1, PRE_ADDSILU = 2 };
+enum { EPI_STORE = 0, EPI_RES, EPI_GATE, EPI_QKV, EPI_HEAD, EPI_LATENT, EPI_CONVTR, EPI_PCM };
+enum { ACT_NONE = 0, ACT_GELU, ACT_SILU, ACT_ELU };
+
+#define NEG_BIG (-1e30f)
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float elu_f(float x) { return x > 0.0f ? x : expm1f(x); }
+
+__device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
+  if (act == ACT_GELU) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
+  else if (act == ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+  else if (act == ACT_ELU) { v.x = elu_f(v.x); v.y = elu_f(v.y); v.z = elu_f(v.z); v.w = elu_f(v.w); }
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Implicit-GEMM: Y[m][n] = epilogue( sum_tap sum_c pre(X[row(m) + tap - halo][c]) * W[n][c][tap] )
+// One kernel serves every Linear, every causal Conv1d (ntaps = kernel) and every ConvTranspose1d
+// (kernel 2s, stride s == causal conv with 2 taps and s*Cout outputs) of the hot path.
+// ---------------------------------------------------------------------------------------------
+struct GemmArgs {
+  // weights, packed [NT][KF][64][4]; bias padded to NT*16
+  const float *W, *bias;
+  int NT, KF, CF, ntaps;
+  // input FM view; double-buffered by frame parity when Xdstride != 0
+  const float *X;
+  long Xdstride;
+  int XF, MT, M, T;  // M = valid rows, T = rows per sequence (multiple of 16 when ntaps > 1)
+  const int *par;    // device frame counter (parity = *par & 1) or null
+  const float *prevec;  // PRE_ADDSILU: per-k vector
+  int epi, act;
+  // output FM view
+  float *Y;
+  long Ydstride;
+  int YF;
+  const float *R;  // residual
+  long Rdstride;
+  int RF;
+  const float *G;  // gate (EPI_GATE)
+  int GF;
+  const float *ls;  // layer scale [N] or null
+  // EPI_QKV
+  float *Q, *Kc, *Vc;
+  const int *offset;
+  const float *freq;  // [32] rotary frequencies
+  int H, Tq, QB, cap, ring;
+  // EPI_HEAD
+  float *eos_logit;
+  uint8_t *is_eos;
+  float eos_thr;
+  int head_nt;  // n-tile holding the EOS row
+  // EPI_LATENT
+  float *lat;  // plain [M][ldim], updated in place
+  float inv_steps;
+  int ldim;
+  // EPI_CONVTR
+  int cout, stride;
+  // EPI_PCM
+  float *pcm;
+};
+
+template <int PRE>
+__device__ __forceinline__ f32x4 pre4(f32x4 x, const float *prevec, int kf, int lane) {
+  if (PRE == PRE_ELU) {
+    x.x = elu_f(x.x); x.y = elu_f(x.y); x.z = elu_f(x.z); x.w = elu_f(x.w);
+  } else if (PRE == PRE_ADDSILU) {
+    f32x4 t = *(const f32x4 *)(prevec + 16 * kf + 4 * (lane >> 4));
+    x.x = silu_f(x.x + t.x); x.y = silu_f(x.y + t.y); x.z = silu_f(x.z + t.z); x.w = silu_f(x.w + t.w);
+  }
+  return x;
+}
+
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 acc, int nt, int mt, int lane, int par) {
+  const int ml = lane & 15, g = lane >> 4;
+  const int m = 16 * mt + ml;
+  const int n0 = 16 * nt + 4 * g;
+  if (a.bias) {
+    f32x4 b = *(const f32x4 *)(a.bias + n0);
+    acc += b;
+  }
+  switch (a.epi) {
+    case EPI_STORE: {
+      acc = act4(acc, a.act);
+      float *y = a.Y + par * a.Ydstride;
+      *(f32x4 *)(y + (((size_t)mt * a.YF + nt) * 64 + lane) * 4) = acc;
+    } break;
+    case EPI_RES: {
+      const float *r = a.R + par * a.Rdstride;
+      f32x4 rv = *(const f32x4 *)(r + (((size_t)mt * a.RF + nt) * 64 + lane) * 4);
+      if (a.ls) acc *= *(const f32x4 *)(a.ls + n0);
+      float *y = a.Y + par * a.Ydstride;
+      *(f32x4 *)(y + (((size_t)mt * a.YF + nt) * 64 + lane) * 4) = rv + acc;
+    } break;
+    case EPI_GATE: {
+      f32x4 rv = *(const f32x4 *)(a.R + (((size_t)mt * a.RF + nt) * 64 + lane) * 4);
+      f32x4 gv = *(const f32x4 *)(a.G + (((size_t)mt * a.GF + nt) * 64 + lane) * 4);
+      *(f32x4 *)(a.Y + (((size_t)mt * a.YF + nt) * 64 + lane) * 4) = rv + gv * acc;
+    } break;
+    case EPI_QKV: {
+      // packed in_proj rows: [q | k | v] x [H][64]  (reference transformer.py:138-143)
+      if (m >= a.M) break;
+      const int D = a.H * 64;
+      const int which = n0 / D;
+      const int hn = n0 - which * D;
+      const int h = hn >> 6, d = hn & 63;
+      const int b = m / a.Tq, t = m - b * a.Tq;
+      const int pos = a.offset[b] + t;
+      if (which < 2) {
+        // interleaved-pair RoPE in fp32 (reference rope.py:28-58)
+        float s0, c0, s1, c1;
+        const float fp = (float)pos;
+        sincosf(a.freq[d >> 1] * fp, &s0, &c0);
+        sincosf(a.freq[(d >> 1) + 1] * fp, &s1, &c1);
+        f32x4 o;
+        o.x = acc.x * c0 - acc.y * s0;
+        o.y = acc.x * s0 + acc.y * c0;
+        o.z = acc.z * c1 - acc.w * s1;
+        o.w = acc.z * s1 + acc.w * c1;
+        acc = o;
+      }
+      const size_t bh = (size_t)b * a.H + h;
+      if (which == 0) {
+        float *q = a.Q + (((bh * a.QB + (t >> 4)) * 4 + (d >> 4)) * 64 + 16 * g + (t & 15)) * 4;
+        *(f32x4 *)q = acc;
+      } else {
+        const int slot = a.ring ? (pos % a.ring) : pos;
+        float *c = (which == 1 ? a.Kc : a.Vc) + (bh * a.cap + slot) * 64 + d;
+        *(f32x4 *)c = acc;
+      }
+    } break;
+    case EPI_HEAD: {
+      if (nt < a.head_nt) {
+        *(f32x4 *)(a.Y + (((size_t)mt * a.YF + nt) * 64 + lane) * 4) = acc;
+      } else if (g == 0 && m < a.M) {
+        if (a.eos_logit) a.eos_logit[m] = acc.x;
+        if (a.is_eos) a.is_eos[m] = acc.x > a.eos_thr ? 1 : 0;
+      }
+    } break;
+    case EPI_LATENT: {
+      // Euler update of lsd_decode: current += flow_dir / num_steps (reference flow_lm.py:39)
+      f32x4 v;
+      if (m < a.M) {
+        float *p = a.lat + (size_t)m * a.ldim + n0;
+        v = *(f32x4 *)p + acc * a.inv_steps;
+        *(f32x4 *)p = v;
+      } else {
+        v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      *(f32x4 *)(a.Y + (((size_t)mt * a.YF + nt) * 64 + lane) * 4) = v;
+    } break;
+    case EPI_CONVTR: {
+      // out[(m*s + j)][n] with n' = j*cout + n (reference conv.py:151-163: overlap-add == 2-tap causal conv)
+      const int j = n0 / a.cout;
+      const int n = n0 - j * a.cout;
+      const size_t mo = (size_t)m * a.stride + j;
+      float *y = a.Y + par * a.Ydstride;
+      *(f32x4 *)(y + (((mo >> 4) * a.YF + (n >> 4)) * 64 + 16 * g + (mo & 15)) * 4) = acc;
+    } break;
+    case EPI_PCM: {
+      if (g == 0 && m < a.M) a.pcm[m] = acc.x;
+    } break;
+  }
+}
+
+// TN x TM 16x16 tiles per wave; WK waves split K (LDS-reduced), WN x WM waves tile N x M.
+template <int TN, int TM, int WK, int WN, int WM, int PRE>
+__global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
+  constexpr int NW = WK * WN * WM;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wk = wave % WK;
+  const int wn = (wave / WK) % WN;
+  const int wm = wave / (WK * WN);
+  const int nt0 = (blockIdx.x * WN + wn) * TN;
+  const int mt0 = (blockIdx.y * WM + wm) * TM;
+  const int par = a.par ? (*a.par & 1) : 0;
+  const float *Xc = a.X + par * a.Xdstride;
+  const float *Xp = a.X + (par ^ 1) * a.Xdstride;
+  const int k0 = (a.KF * wk) / WK, k1 = (a.KF * (wk + 1)) / WK;
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const float *wb[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    int nt = nt0 + i < a.NT ? nt0 + i : a.NT - 1;
+    wb[i] = a.W + (size_t)nt * a.KF * 256 + lane * 4;
+  }
+  int mtc[TM], tin[TM], bT[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    int mt = mt0 + j < a.MT ? mt0 + j : a.MT - 1;
+    mtc[j] = mt;
+    int row = 16 * mt + (lane & 15);
+    int t = a.ntaps > 1 ? row % a.T : 0;
+    tin[j] = t;
+    bT[j] = row - t;
+  }
+  int tap = 0, cf = k0;
+  if (a.ntaps > 1) {
+    tap = k0 / a.CF;
+    cf = k0 - tap * a.CF;
+  }
+  const int halo = a.ntaps - 1;
+  // U fragments per step: all 1 KiB loads of a step are issued before the first MFMA consumes one
+  constexpr int U = (TN * TM <= 2) ? 8 : 4;
+  auto step = [&](auto uc, int kf) {
+    constexpr int UU = decltype(uc)::value;
+    f32x4 w[UU][TN], x[UU][TM];
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        // weights are read exactly once by the K-split (decode) configuration: stream them non-temporally
+        if constexpr (WK > 1) w[u][i] = __builtin_nontemporal_load((const f32x4 *)(wb[i] + (size_t)(kf + u) * 256));
+        else w[u][i] = *(const f32x4 *)(wb[i] + (size_t)(kf + u) * 256);
+      }
+      if (a.ntaps == 1) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          x[u][j] = *(const f32x4 *)(Xc + (((size_t)mtc[j] * a.XF + kf + u) * 64 + lane) * 4);
+      } else {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          int ts = tin[j] + tap - halo;
+          const float *src = ts >= 0 ? Xc : Xp;
+          int rr = bT[j] + (ts >= 0 ? ts : a.T + ts);
+          x[u][j] = *(const f32x4 *)(src + (((size_t)(rr >> 4) * a.XF + cf) * 64 + (lane & 48) + (rr & 15)) * 4);
+        }
+        if (++cf == a.CF) { cf = 0; ++tap; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j) x[u][j] = pre4<PRE>(x[u][j], a.prevec, kf + u, lane);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][i].x, x[u][j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][i].y, x[u][j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][i].z, x[u][j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][i].w, x[u][j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+  int kf = k0;
+  for (; kf + U <= k1; kf += U) step(std::integral_constant<int, U>{}, kf);
+  for (; kf < k1; ++kf) step(std::integral_constant<int, 1>{}, kf);
+
+  if constexpr (WK > 1) {
+    __shared__ f32x4 red[(WK - 1) * WN * WM * TN * TM * 64];
+    const int grp = wave / WK;  // (wn, wm) group
+    if (wk > 0) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          red[((((wk - 1) * WN * WM + grp) * TN + i) * TM + j) * 64 + lane] = acc[i][j];
+    }
+    __syncthreads();
+    if (wk == 0) {
+      for (int s = 0; s < WK - 1; ++s)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[i][j] += red[(((s * WN * WM + grp) * TN + i) * TM + j) * 64 + lane];
+    }
+  }
+  if (wk == 0) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        if (nt0 + i < a.NT && mt0 + j < a.MT) gemm_epilogue(a, acc[i][j], nt0 + i, mt0 + j, lane, par);
+  }
+  (void)NW;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight packing (load time).  mode 0: Linear / Conv1d weight [N][C][ntaps] -> value(n, c, tap);
+// mode 1: ConvTranspose1d weight [C][cout][2s] viewed as a 2-tap conv with n' = j*cout + n:
+//         tap 1 (current input row) uses kernel index j, tap 0 (previous row) uses j + s.
+// dst[nt][tap*CF + cf][lane][j4] = W[n = 16nt + (lane&15)][c = 16cf + 4(lane>>4) + j4][tap]
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_weight_kernel(const float *src, float *dst, int N, int C, int ntaps, int mode, int cout,
+                                   int stride, int nt_off, int KF, long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int j4 = i & 3;
+  int lane = (i >> 2) & 63;
+  long f = i >> 8;
+  int kf = f % KF;
+  int nt = f / KF;
+  int CF = C / 16;
+  int tap = kf / CF, cf = kf - tap * CF;
+  int n = 16 * nt + (lane & 15);
+  int c = 16 * cf + 4 * (lane >> 4) + j4;
+  float v = 0.f;
+  if (n < N) {
+    if (mode == 0) {
+      v = src[((size_t)n * C + c) * ntaps + tap];
+    } else {
+      int j = n / cout, nn = n - j * cout;
+      int kidx = tap == 1 ? j : j + stride;
+      v = src[((size_t)c * cout + nn) * (2 * stride) + kidx];
+    }
+  }
+  dst[((size_t)(nt + nt_off) * KF) * 256 + (size_t)kf * 256 + lane * 4 + j4] = v;
+}
+
+__global__ void pack_bias_kernel(const float *src, float *dst, int N, int mode, int cout, int n_off, int Npad) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Npad) return;
+  float v = 0.f;
+  if (i < N && src) v = mode == 0 ? src[i] : src[i % cout];
+  dst[n_off + i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Layout conversion: row-major [M][K] <-> FM.  One thread per float4.
+// ---------------------------------------------------------------------------------------------
+__global__ void to_fm_kernel(const float *src, float *dst, int M, int K, int MT) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int KF = K / 16;
+  long total = (long)MT * KF * 64;
+  if (i >= total) return;
+  int lane = i & 63;
+  long f = i >> 6;
+  int kf = f % KF;
+  int mt = f / KF;
+  int m = 16 * mt + (lane & 15);
+  int k = 16 * kf + 4 * (lane >> 4);
+  f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (m < M) v = *(const f32x4 *)(src + (size_t)m * K + k);
+  *(f32x4 *)(dst + i * 4) = v;
+}
+
+__global__ void from_fm_kernel(const float *src, float *dst, int M, int K, int F, int f_off) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int K4 = K / 4;
+  if (i >= (long)M * K4) return;
+  int m = i / K4;
+  int k = (i - (long)m * K4) * 4;
+  int kf = k >> 4;
+  const float *p = src + (((size_t)(m >> 4) * F + kf + f_off) * 64 + 16 * ((k & 15) >> 2) + (m & 15)) * 4;
+  *(f32x4 *)(dst + (size_t)m * K + k) = *(const f32x4 *)p;
+}
+
+// FlowLM step input: latent (external or the previous output; NaN = BOS -> bos_emb, reference
+// flow_lm.py:121) to FM; LSD start point: noise (or zeros) to the plain `lat` buffer and its FM copy.
+__global__ void prep_lm_kernel(const float *lat_in, const float *bos, const float *noise, float *x_fm, float *lat,
+                               float *lat_fm, int B, int ldim, int MT) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int KF = ldim / 16;
+  if (i >= MT * KF * 64) return;
+  int lane = i & 63;
+  int f = i >> 6;
+  int kf = f % KF, mt = f / KF;
+  int m = 16 * mt + (lane & 15);
+  int k = 16 * kf + 4 * (lane >> 4);
+  f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f}, z = v;
+  if (m < B) {
+    v = *(const f32x4 *)(lat_in + (size_t)m * ldim + k);
+    f32x4 b = *(const f32x4 *)(bos + k);
+    v.x = v.x != v.x ? b.x : v.x;
+    v.y = v.y != v.y ? b.y : v.y;
+    v.z = v.z != v.z ? b.z : v.z;
+    v.w = v.w != v.w ? b.w : v.w;
+    if (noise) z = *(const f32x4 *)(noise + (size_t)m * ldim + k);
+  }
+  *(f32x4 *)(x_fm + (size_t)i * 4) = v;
+  *(f32x4 *)(lat_fm + (size_t)i * 4) = z;
+  if (m < B) *(f32x4 *)(lat + (size_t)m * ldim + k) = z;
+}
+
+// Mimi input: latent * emb_std + emb_mean (reference tts_model.py:449) to FM
+__global__ void prep_mimi_kernel(const float *lat, const float *std, const float *mean, float *z_fm, int B, int ldim,
+                                 int MT) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int KF = ldim / 16;
+  if (i >= MT * KF * 64) return;
+  int lane = i & 63;
+  int f = i >> 6;
+  int kf = f % KF, mt = f / KF;
+  int m = 16 * mt + (lane & 15);
+  int k = 16 * kf + 4 * (lane >> 4);
+  f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (m < B) v = *(const f32x4 *)(lat + (size_t)m * ldim + k) * *(const f32x4 *)(std + k) + *(const f32x4 *)(mean + k);
+  *(f32x4 *)(z_fm + (size_t)i * 4) = v;
+}
+
+// Depthwise ConvTranspose1d k = 2s, stride s on one input step per frame (reference resample.py:40-51,
+// conv.py:151-163): out[b, t, c] = z[b, c] w[c, t] + z_prev[b, c] w[c, s + t].  z is double-buffered by
+// frame parity, so `partial` never has to be materialised.
+__global__ void upsample_kernel(const float *zq, long zdstride, const int *par_p, const float *w, float *out, int B,
+                                int C, int s) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int C4 = C / 4;
+  long total = (long)B * s * C4;
+  if (i >= total) return;
+  int c = (i % C4) * 4;
+  long r = i / C4;
+  int t = r % s;
+  int b = r / s;
+  int par = *par_p & 1;
+  int CF = C / 16;
+  size_t zi = (((size_t)(b >> 4) * CF + (c >> 4)) * 64 + 16 * ((c & 15) >> 2) + (b & 15)) * 4;
+  f32x4 zc = *(const f32x4 *)(zq + par * zdstride + zi);
+  f32x4 zp = *(const f32x4 *)(zq + (par ^ 1) * zdstride + zi);
+  f32x4 o;
+  const int k2 = 2 * s;
+  o.x = zc.x * w[(c + 0) * k2 + t] + zp.x * w[(c + 0) * k2 + s + t];
+  o.y = zc.y * w[(c + 1) * k2 + t] + zp.y * w[(c + 1) * k2 + s + t];
+  o.z = zc.z * w[(c + 2) * k2 + t] + zp.z * w[(c + 2) * k2 + s + t];
+  o.w = zc.w * w[(c + 3) * k2 + t] + zp.w * w[(c + 3) * k2 + s + t];
+  long m = (long)b * s + t;
+  *(f32x4 *)(out + (((size_t)(m >> 4) * CF + (c >> 4)) * 64 + 16 * ((c & 15) >> 2) + (m & 15)) * 4) = o;
+}
+
+__global__ void add_int_kernel(int *p, int n, int inc) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] += inc;
+}
+__global__ void set_int_kernel(int *p, int n, int v) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void fill_kernel(float *p, long n, float v) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over K of an FM tensor (biased variance), optional affine and AdaLN modulate
+// (reference nn.LayerNorm eps 1e-5: mimi_transformer.py:26-27; flow MLP LayerNorm eps 1e-6 +
+// modulate: mlp.py:16-17,49-55,109).  One 256-thread block per 16-row tile; wave w owns KF/4 fragments
+// in registers, two-pass mean / variance, cross-wave reduction through LDS.
+// ---------------------------------------------------------------------------------------------
+struct LnArgs {
+  const float *X;
+  long Xdstride;
+  int XF;
+  float *Y;
+  int YF;
+  const float *w, *b;        // [K] or null
+  const float *shift, *scale;  // FM views (row stride SF) or null
+  int SF;
+  int KF;
+  float eps;
+  const int *par;
+};
+
+__global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
+  const int mt = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int par = a.par ? (*a.par & 1) : 0;
+  const float *X = a.X + par * a.Xdstride;
+  const int k0 = (a.KF * wave) / 4, k1 = (a.KF * (wave + 1)) / 4;
+  f32x4 v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int kf = k0 + i;
+    if (kf < k1) {
+      v[i] = *(const f32x4 *)(X + (((size_t)mt * a.XF + kf) * 64 + lane) * 4);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  __shared__ float red[2][4][16];
+  s += __shfl_xor(s, 16);
+  s += __shfl_xor(s, 32);
+  if (lane < 16) red[0][wave][lane] = s;
+  __syncthreads();
+  const int ml = lane & 15;
+  const float K = (float)(a.KF * 16);
+  const float mean = (red[0][0][ml] + red[0][1][ml] + red[0][2][ml] + red[0][3][ml]) / K;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int kf = k0 + i;
+    if (kf < k1) {
+      f32x4 d = v[i] - mean;
+      q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+  }
+  q += __shfl_xor(q, 16);
+  q += __shfl_xor(q, 32);
+  if (lane < 16) red[1][wave][lane] = q;
+  __syncthreads();
+  const float var = (red[1][0][ml] + red[1][1][ml] + red[1][2][ml] + red[1][3][ml]) / K;
+  const float rstd = 1.0f / sqrtf(var + a.eps);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int kf = k0 + i;
+    if (kf < k1) {
+      f32x4 y = (v[i] - mean) * rstd;
+      const int k = 16 * kf + 4 * (lane >> 4);
+      if (a.w) y = y * *(const f32x4 *)(a.w + k) + *(const f32x4 *)(a.b + k);
+      if (a.scale) {
+        f32x4 sc = *(const f32x4 *)(a.scale + (((size_t)mt * a.SF + kf) * 64 + lane) * 4);
+        f32x4 sh = *(const f32x4 *)(a.shift + (((size_t)mt * a.SF + kf) * 64 + lane) * 4);
+        y = y * (1.0f + sc) + sh;
+      }
+      *(f32x4 *)(a.Y + (((size_t)mt * a.YF + kf) * 64 + lane) * 4) = y;
+    }
+  }
+}
+
+// The flow MLP's variance-based "RMSNorm" on one row + average of the two time embeddings
+// (reference mlp.py:20-25,70,204-206).  Load-time constant folding, one wave.
+__global__ void tcomb_kernel(const float *h0_fm, const float *h1_fm, const float *alpha0, const float *alpha1,
+                             float *out, int fd) {
+  // row 0 of an FM tensor with F = fd/16: element k at ((k/16)*64 + 16*((k%16)/4))*4 + k%4
+  const int lane = threadIdx.x;
+  auto at = [&](const float *p, int k) { return p[((size_t)(k >> 4) * 64 + 16 * ((k & 15) >> 2)) * 4 + (k & 3)]; };
+  float r[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  for (int e = 0; e < 2; ++e) {
+    const float *p = e ? h1_fm : h0_fm;
+    float s = 0.f;
+    for (int k = lane; k < fd; k += 64) s += at(p, k);
+    for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+    float mean = s / fd, q = 0.f;
+    for (int k = lane; k < fd; k += 64) { float d = at(p, k) - mean; q += d * d; }
+    for (int o = 32; o; o >>= 1) q += __shfl_xor(q, o);
+    r[e][0] = 1.0f / sqrtf(1e-5f + q / (fd - 1));  // unbiased variance
+  }
+  for (int k = lane; k < fd; k += 64)
+    out[k] = (at(h0_fm, k) * (alpha0[k] * r[0][0]) + at(h1_fm, k) * (alpha1[k] * r[1][0])) * 0.5f;
+}
+
+// cat(cos(t f), sin(t f)) for one scalar t -> FM row 0 (reference mlp.py:79-81)
+__global__ void timestep_embed_kernel(const float *freqs, float t, float *e_fm, int half) {
+  int k = threadIdx.x + blockIdx.x * blockDim.x;
+  if (k >= 2 * half) return;
+  float arg = t * freqs[k % half];
+  float v = k < half ? cosf(arg) : sinf(arg);
+  e_fm[((size_t)(k >> 4) * 64 + 16 * ((k & 15) >> 2)) * 4 + (k & 3)] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Streaming attention on the KV cache, all on fp32 MFMA, no LDS.  One wave per (sequence, head,
+// 16-query block, key split).  S^T = K Q^T puts the query on the lane (softmax reductions are two
+// xor-shuffles), and its accumulator is directly the A operand of O = P V.
+// Causal + optional sliding-window mask (reference transformer.py:22-29); cache is linear (FlowLM)
+// or a ring of `ring` slots (Mimi decoder, context 250).
+// ---------------------------------------------------------------------------------------------
+struct AttnArgs {
+  const float *Q, *Kc, *Vc;
+  const int *offset;
+  int H, Tq, QB, cap, ring, ctx, splits;
+  float *part;  // [BH*QB][splits][16][64 + 2 (pad to 80)]
+  float *Y;
+  int YF;
+};
+#define ATT_PSTRIDE 80
+
+__device__ __forceinline__ void attn_store_out(const AttnArgs &a, int b, int h, int qb, int nq, int lane, f32x4 o[4],
+                                               float linv_for_row[4]) {
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qi = 4 * g + r;
+    if (qi < nq) {
+      const size_t m = (size_t)b * a.Tq + 16 * qb + qi;
+      f32x4 v;
+      v.x = o[0][r] * linv_for_row[r];
+      v.y = o[1][r] * linv_for_row[r];
+      v.z = o[2][r] * linv_for_row[r];
+      v.w = o[3][r] * linv_for_row[r];
+      // column n = h*64 + 4c + j -> fragment 4h + c/4, k-group c%4
+      *(f32x4 *)(a.Y + (((m >> 4) * a.YF + 4 * h + (c >> 2)) * 64 + 16 * (c & 3) + (m & 15)) * 4) = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
+  const int bh = blockIdx.x, qb = blockIdx.y, sp = blockIdx.z;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+  const int off = a.offset[b];
+  const int q0 = off + 16 * qb;
+  const int nq = min(16, a.Tq - 16 * qb);
+  const int klo = a.ctx > 0 ? max(0, q0 - a.ctx + 1) : 0;
+  const int khi = q0 + nq;
+  const int tile_lo = klo >> 4, tile_hi = (khi + 15) >> 4;
+  const int per = (tile_hi - tile_lo + a.splits - 1) / a.splits;
+  const int ts = tile_lo + sp * per;
+  const int te = min(tile_hi, ts + per);
+
+  f32x4 qf[4];
+#pragma unroll
+  for (int df = 0; df < 4; ++df)
+    qf[df] = *(const f32x4 *)(a.Q + ((((size_t)bh * a.QB + qb) * 4 + df) * 64 + lane) * 4) * 0.125f;  // 1/sqrt(64)
+
+  f32x4 o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = NEG_BIG, l_run = 0.f;
+  const float *Kb = a.Kc + (size_t)bh * a.cap * 64;
+  const float *Vb = a.Vc + (size_t)bh * a.cap * 64;
+  const int pq = q0 + c;
+
+  for (int tile = ts; tile < te; ++tile) {
+    const int p0 = tile * 16;
+    const int slot0 = a.ring ? (p0 % a.ring) : p0;
+    f32x4 kf4[4], vf4[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) kf4[df] = *(const f32x4 *)(Kb + (size_t)(slot0 + c) * 64 + 16 * df + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vf4[r] = *(const f32x4 *)(Vb + (size_t)(slot0 + 4 * g + r) * 64 + 4 * c);
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf4[df].x, qf[df].x, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf4[df].y, qf[df].y, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf4[df].z, qf[df].z, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf4[df].w, qf[df].w, s, 0, 0, 0);
+    }
+    // s[r] = score(key p0 + 4g + r, query c)
+    bool ok[4];
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int pk = p0 + 4 * g + r;
+      ok[r] = (c < nq) && (pk <= pq) && (a.ctx <= 0 || pq - pk < a.ctx);
+      mx = ok[r] ? fmaxf(mx, s[r]) : mx;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = expf(m_run - m_new);
+    f32x4 p;
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p[r] = ok[r] ? expf(s[r] - m_new) : 0.f;
+      ps += p[r];
+    }
+    ps += __shfl_xor(ps, 16);
+    ps += __shfl_xor(ps, 32);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+    // rescale the accumulator rows (query 4g + r lives in lane 4g + r of the score layout)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ar = __shfl(alpha, 4 * g + r);
+      o[0][r] *= ar; o[1][r] *= ar; o[2][r] *= ar; o[3][r] *= ar;
+    }
+    // O[query][d = 4c' + j] += sum_key P[query][key] V[key][4c' + j]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], vf4[r].x, o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], vf4[r].y, o[1], 0, 0, 0);
+      o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], vf4[r].z, o[2], 0, 0, 0);
+      o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], vf4[r].w, o[3], 0, 0, 0);
+    }
+  }
+
+  if (a.splits == 1) {
+    float linv[4];
+    const float li = 1.0f / l_run;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) linv[r] = __shfl(li, 4 * g + r);
+    attn_store_out(a, b, h, qb, nq, lane, o, linv);
+  } else {
+    float *pp = a.part + (((size_t)bh * a.QB + qb) * a.splits + sp) * 16 * ATT_PSTRIDE;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      f32x4 v;
+      v.x = o[0][r]; v.y = o[1][r]; v.z = o[2][r]; v.w = o[3][r];
+      *(f32x4 *)(pp + (4 * g + r) * ATT_PSTRIDE + 4 * c) = v;
+    }
+    if (g == 0) {
+      pp[c * ATT_PSTRIDE + 64] = m_run;
+      pp[c * ATT_PSTRIDE + 65] = l_run;
+    }
+  }
+}
+
+// merges the key splits: thread (query, 4-wide d group)
+__global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs a) {
+  const int bh = blockIdx.x, qb = blockIdx.y;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int qi = threadIdx.x >> 4, c = threadIdx.x & 15;
+  const int nq = min(16, a.Tq - 16 * qb);
+  if (qi >= nq) return;
+  const float *pp = a.part + (((size_t)bh * a.QB + qb) * a.splits) * 16 * ATT_PSTRIDE + qi * ATT_PSTRIDE;
+  float M = NEG_BIG;
+  for (int s = 0; s < a.splits; ++s) M = fmaxf(M, pp[(size_t)s * 16 * ATT_PSTRIDE + 64]);
+  float L = 0.f;
+  f32x4 O = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < a.splits; ++s) {
+    const float *ps = pp + (size_t)s * 16 * ATT_PSTRIDE;
+    const float w = expf(ps[64] - M);
+    L += ps[65] * w;
+    O += *(const f32x4 *)(ps + 4 * c) * w;
+  }
+  O = O * (1.0f / L);
+  const size_t m = (size_t)b * a.Tq + 16 * qb + qi;
+  *(f32x4 *)(a.Y + (((m >> 4) * a.YF + 4 * h + (c >> 2)) * 64 + 16 * (c & 3) + (m & 15)) * 4) = O;
+}
+
+// ---------------------------------------------------------------------------------------------
+// KV cache import / export between the reference layout f32[2, B, T, H, 64] (transformer.py:32-36)
+// and the internal K[b][h][slot][64], V[b][h][slot][64].
+// ---------------------------------------------------------------------------------------------
+__global__ void kv_import_kernel(const float *src, float *Kc, float *Vc, int B, int srcB, int T, int H, int cap) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over [2][B][T][H][16 float4]
+  long total = 2L * B * T * H * 16;
+  if (i >= total) return;
+  int d4 = i & 15;
+  long r = i >> 4;
+  int h = r % H; r /= H;
+  int t = r % T; r /= T;
+  int b = r % B; r /= B;
+  int which = (int)r;
+  int sb = srcB == 1 ? 0 : b;
+  f32x4 v = *(const f32x4 *)(src + ((((size_t)which * srcB + sb) * T + t) * H + h) * 64 + d4 * 4);
+  float *dst = which ? Vc : Kc;
+  *(f32x4 *)(dst + (((size_t)b * H + h) * cap + t) * 64 + d4 * 4) = v;
+}
+
+__global__ void kv_export_kernel(float *dst, const float *Kc, const float *Vc, int B, int T, int H, int cap) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = 2L * B * T * H * 16;
+  if (i >= total) return;
+  int d4 = i & 15;
+  long r = i >> 4;
+  int h = r % H; r /= H;
+  int t = r % T; r /= T;
+  int b = r % B; r /= B;
+  int which = (int)r;
+  const float *src = which ? Vc : Kc;
+  f32x4 v = *(const f32x4 *)(src + (((size_t)b * H + h) * cap + t) * 64 + d4 * 4);
+  *(f32x4 *)(dst + ((((size_t)which * B + b) * T + t) * H + h) * 64 + d4 * 4) = v;
+}
+
+// dst rows <- src rows (src batch 1 broadcasts), whole [L][2][B][H][cap][64] block, equal cap
+__global__ void kv_copy_kernel(float *dst, const float *src, long per_row, int B, int srcB, int planes) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // float4 units over [planes][B][per_row/4]
+  long pr4 = per_row / 4;
+  long total = (long)planes * B * pr4;
+  if (i >= total) return;
+  long e = i % pr4;
+  long r = i / pr4;
+  int b = r % B;
+  int pl = r / B;
+  int sb = srcB == 1 ? 0 : b;
+  *(f32x4 *)(dst + ((size_t)pl * B + b) * per_row + e * 4) = *(const f32x4 *)(src + ((size_t)pl * srcB + sb) * per_row + e * 4);
+}

@@ -1,0 +1,297 @@
+"""Python host wrapper over the C ABI (include/ptts.h).  PyTorch-ROCm is used only for device
+memory and streams; all arithmetic of the hot path runs in libptts.so.
+
+Mirrors the reference's internal seam:
+  * `Engine.lm_prefill / lm_decode_step`  <->  `TTSModel._run_flow_lm_and_increment_step`
+    (reference tts_model.py:317-346)
+  * `Engine.mimi_decode`                  <->  the body of `_decode_audio_worker`
+    (reference tts_model.py:444-455) = de-normalise + quantizer + `MimiModel.decode_from_latent`
+  * `LMState` / `MimiState`               <->  `init_states(...)` dicts (reference stateful_module.py:7-16)
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import Config
+from .weights import state_dict_spec
+
+
+def _ptr(t: torch.Tensor | None):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def make_ptts_config(cfg: Config) -> _lib.PttsConfig:
+    t, m, sn = cfg.flow_lm.transformer, cfg.mimi.transformer, cfg.mimi.seanet
+    if len(sn.ratios) != 3:
+        raise ValueError("SEANet decoder with 3 upsampling stages expected")
+    pc = _lib.PttsConfig()
+    pc.d_model, pc.num_heads, pc.num_layers = t.d_model, t.num_heads, t.num_layers
+    pc.ff_dim = t.d_model * t.hidden_scale
+    pc.ldim = cfg.mimi.quantizer.dimension
+    pc.flow_dim, pc.flow_depth = cfg.flow_lm.flow.dim, cfg.flow_lm.flow.depth
+    pc.max_period = float(t.max_period)
+    pc.m_dim, pc.m_heads, pc.m_layers, pc.m_ff = m.d_model, m.num_heads, m.num_layers, m.dim_feedforward
+    pc.m_context = m.context
+    pc.m_max_period = float(m.max_period)
+    pc.n_filters = sn.n_filters
+    pc.ratios = (C.c_int32 * 3)(*[int(r) for r in sn.ratios])
+    pc.kernel_size, pc.res_kernel_size, pc.last_kernel_size = sn.kernel_size, sn.residual_kernel_size, sn.last_kernel_size
+    pc.compress = sn.compress
+    pc.upsample_stride = cfg.upsample_stride
+    return pc
+
+
+class LMState:
+    """FlowLM KV caches of `batch` sequences with capacity `t_cap` positions."""
+
+    def __init__(self, engine: "Engine", batch: int, t_cap: int):
+        self.engine, self.batch, self.t_cap = engine, batch, t_cap
+        h = C.c_void_p()
+        _lib.check(engine.lib.ptts_lm_state_create(engine.handle, batch, t_cap, C.byref(h)))
+        self.handle = h
+        engine._states.add(self)
+
+    def close(self):
+        if self.handle is not None:
+            self.engine.lib.ptts_lm_state_destroy(self.handle)
+            self.handle = None
+
+    def reset(self):
+        _lib.check(self.engine.lib.ptts_lm_state_reset(self.handle, None))
+
+    def offsets(self) -> np.ndarray:
+        out = (C.c_int32 * self.batch)()
+        _lib.check(self.engine.lib.ptts_lm_state_offsets(self.handle, out, None))
+        return np.array(out[:], dtype=np.int64)
+
+    def import_layer(self, layer: int, cache: torch.Tensor, t: int):
+        """cache: f32[2, Bsrc, >=t, H, 64] in the reference layout (reference transformer.py:32-36)."""
+        cache = cache[:, :, :t].to(self.engine.device, torch.float32).contiguous()
+        self.engine._pre()
+        _lib.check(self.engine.lib.ptts_lm_state_import(self.handle, layer, _ptr(cache), cache.shape[1], t, None))
+        self.engine.sync()
+
+    def export_layer(self, layer: int, t: int) -> torch.Tensor:
+        e = self.engine
+        out = torch.empty((2, self.batch, t, e.H, 64), dtype=torch.float32, device=e.device)
+        _lib.check(e.lib.ptts_lm_state_export(self.handle, layer, _ptr(out), t, None))
+        e.sync()
+        return out
+
+    def copy_from(self, src: "LMState"):
+        _lib.check(self.engine.lib.ptts_lm_state_copy(self.handle, src.handle, None))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MimiState:
+    def __init__(self, engine: "Engine", batch: int):
+        self.engine, self.batch = engine, batch
+        h = C.c_void_p()
+        _lib.check(engine.lib.ptts_mimi_state_create(engine.handle, batch, C.byref(h)))
+        self.handle = h
+        engine._states.add(self)
+
+    def close(self):
+        if self.handle is not None:
+            self.engine.lib.ptts_mimi_state_destroy(self.handle)
+            self.handle = None
+
+    def reset(self):
+        _lib.check(self.engine.lib.ptts_mimi_state_reset(self.handle, None))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    """Weights of one model on one GPU + entry points of the hot path."""
+
+    def __init__(self, cfg: Config, weights: dict, device: str | torch.device = "cuda:0"):
+        self.lib = _lib.load()
+        self.handle = None
+        self._states = weakref.WeakSet()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("pocket_tts_amd runs on a ROCm GPU only (device must be cuda:N)")
+        torch.cuda.set_device(self.device)
+        spec = state_dict_spec(cfg)
+        keep, arr = [], (_lib.PttsTensor * len(spec))()
+        for i, (name, shape) in enumerate(spec.items()):
+            if name not in weights:
+                raise KeyError(f"checkpoint is missing tensor {name}")
+            w = weights[name]
+            if isinstance(w, np.ndarray):
+                w = torch.from_numpy(w)
+            if tuple(w.shape) != tuple(shape):
+                raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(w.shape)}")
+            w = w.to(self.device, torch.float32).contiguous()
+            keep.append(w)
+            arr[i].name = name.encode()
+            arr[i].d_data = w.data_ptr()
+            arr[i].numel = w.numel()
+        torch.cuda.synchronize(self.device)
+        pc = make_ptts_config(cfg)
+        h = C.c_void_p()
+        _lib.check(self.lib.ptts_create(C.byref(pc), arr, len(spec), self.device.index or 0, C.byref(h)))
+        self.handle = h
+        del keep
+        # the library's stream, visible to torch so that tensor ops can be ordered against it
+        self.stream = torch.cuda.ExternalStream(self.lib.ptts_engine_stream(h), device=self.device)
+        t = cfg.flow_lm.transformer
+        self.D, self.H, self.L = t.d_model, t.num_heads, t.num_layers
+        self.ldim = cfg.mimi.quantizer.dimension
+        self.frame_samples = cfg.frame_samples
+        # embedding table + voice-path parameters stay as torch tensors (gather / prefill inputs)
+        self.embed = torch.as_tensor(weights["flow_lm.conditioner.embed.weight"]).to(self.device, torch.float32)
+        self.bos_before_voice = None
+        if "flow_lm.bos_before_voice" in weights:
+            self.bos_before_voice = torch.as_tensor(weights["flow_lm.bos_before_voice"]).to(self.device, torch.float32)
+
+    # ---- stream ordering between torch's current stream and the engine stream
+    def _pre(self):
+        """engine stream waits for work already queued on torch's current stream (inputs)"""
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def _post(self):
+        """torch's current stream waits for the engine stream (outputs)"""
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    # ---- utilities
+    def sync(self):
+        _lib.check(self.lib.ptts_sync(self.handle, None))
+
+    @property
+    def stream_ptr(self):
+        return self.lib.ptts_engine_stream(self.handle)
+
+    def timer_start(self):
+        _lib.check(self.lib.ptts_timer_start(self.handle, None))
+
+    def timer_stop_ms(self) -> float:
+        ms = C.c_float()
+        _lib.check(self.lib.ptts_timer_stop_ms(self.handle, None, C.byref(ms)))
+        return ms.value
+
+    def lm_weight_bytes(self) -> int:
+        return self.lib.ptts_lm_weight_bytes(self.handle)
+
+    def mimi_weight_bytes(self) -> int:
+        return self.lib.ptts_mimi_weight_bytes(self.handle)
+
+    def new_lm_state(self, batch: int, t_cap: int) -> LMState:
+        return LMState(self, batch, t_cap)
+
+    def new_mimi_state(self, batch: int) -> MimiState:
+        return MimiState(self, batch)
+
+    # ---- FlowLM
+    def embed_text(self, tokens: torch.Tensor) -> torch.Tensor:
+        """`LUTConditioner._get_condition` gather (reference text.py:74-76); prefill input only."""
+        return self.embed[tokens.to(self.device)]
+
+    def lm_prefill(self, state: LMState, emb: torch.Tensor):
+        """emb f32[B, T, D]: text embeddings or voice conditioning (reference tts_model.py:722-725,899)."""
+        emb = emb.to(self.device, torch.float32).contiguous()
+        if emb.dim() != 3 or emb.shape[0] != state.batch or emb.shape[2] != self.D:
+            raise ValueError(f"prefill expects [B={state.batch}, T, {self.D}], got {tuple(emb.shape)}")
+        self._pre()
+        _lib.check(self.lib.ptts_lm_prefill(self.handle, state.handle, _ptr(emb), emb.shape[1], None))
+        emb.record_stream(self.stream)
+        self._post()
+
+    def lm_decode_step(self, state: LMState, latent_in=None, noise=None, lsd_steps: int = 1,
+                       eos_threshold: float = -4.0, out_latent=None, out_logit=None, out_eos=None):
+        """One autoregressive step (reference tts_model.py:758-760, flow_lm.py:96-139).  Asynchronous on
+        the engine stream; outputs are device tensors (allocated if not given)."""
+        B = state.batch
+        dev = self.device
+        out_latent = torch.empty((B, self.ldim), dtype=torch.float32, device=dev) if out_latent is None else out_latent
+        out_logit = torch.empty((B,), dtype=torch.float32, device=dev) if out_logit is None else out_logit
+        out_eos = torch.empty((B,), dtype=torch.uint8, device=dev) if out_eos is None else out_eos
+        self._pre()
+        _lib.check(self.lib.ptts_lm_decode_step(
+            self.handle, state.handle, _ptr(latent_in), _ptr(noise), lsd_steps, eos_threshold,
+            _ptr(out_latent), _ptr(out_logit), _ptr(out_eos), None))
+        for t in (latent_in, noise, out_latent, out_logit, out_eos):
+            if t is not None:
+                t.record_stream(self.stream)
+        self._post()
+        return out_latent, out_logit, out_eos
+
+    def lm_latent(self, state: LMState) -> int:
+        return self.lib.ptts_lm_latent_ptr(state.handle)
+
+    def capture_lm_step(self, state: LMState, noise, lsd_steps, eos_threshold, out_latent, out_logit, out_eos):
+        g = C.c_void_p()
+        _lib.check(self.lib.ptts_graph_capture_lm_step(
+            self.handle, state.handle, _ptr(noise), lsd_steps, eos_threshold, _ptr(out_latent), _ptr(out_logit),
+            _ptr(out_eos), C.byref(g)))
+        return g
+
+    def capture_mimi(self, state: MimiState, latent, pcm: torch.Tensor):
+        """latent: device tensor f32[B, ldim] or a raw device pointer (e.g. `lm_latent(state)`)."""
+        g = C.c_void_p()
+        lp = C.c_void_p(latent) if isinstance(latent, int) else _ptr(latent)
+        _lib.check(self.lib.ptts_graph_capture_mimi(self.handle, state.handle, lp, _ptr(pcm), C.byref(g)))
+        return g
+
+    def graph_launch(self, g):
+        _lib.check(self.lib.ptts_graph_launch(g, None))
+
+    def graph_destroy(self, g):
+        self.lib.ptts_graph_destroy(g)
+
+    # ---- Mimi
+    def mimi_decode(self, state: MimiState, latent: torch.Tensor, out_pcm=None) -> torch.Tensor:
+        """latent f32[B, ldim] (normalised FlowLM output) -> pcm f32[B, frame_samples]."""
+        B = state.batch
+        if out_pcm is None:
+            out_pcm = torch.empty((B, self.frame_samples), dtype=torch.float32, device=self.device)
+        self._pre()
+        _lib.check(self.lib.ptts_mimi_decode(self.handle, state.handle, _ptr(latent), _ptr(out_pcm), None))
+        latent.record_stream(self.stream)
+        out_pcm.record_stream(self.stream)
+        self._post()
+        return out_pcm
+
+    def debug_read(self, state, name: str) -> torch.Tensor:
+        is_mimi = isinstance(state, MimiState)
+        cap = 64 * 1024 * 1024
+        buf = torch.empty((cap,), dtype=torch.float32, device=self.device)
+        self._pre()
+        r, c = C.c_int32(), C.c_int32()
+        n = self.lib.ptts_debug_read(self.handle, state.handle, int(is_mimi), name.encode(), _ptr(buf), cap,
+                                     C.byref(r), C.byref(c), None)
+        _lib.check(int(n))
+        self.sync()
+        return buf[: r.value * c.value].view(r.value, c.value).clone()
+
+    def close(self):
+        """Destroys every state created from this engine, then the engine (order matters: states
+        point into the engine)."""
+        if self.handle is not None:
+            for st in list(self._states):
+                st.close()
+            self.lib.ptts_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
