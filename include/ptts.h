@@ -65,7 +65,8 @@ int ptts_lm_state_reset(ptts_lm_state *s, void *stream);
 int ptts_lm_state_import(ptts_lm_state *s, int32_t layer, const float *d_cache, int32_t src_batch,
                          int32_t t, void *stream);
 int ptts_lm_state_export(ptts_lm_state *s, int32_t layer, float *d_cache, int32_t t, void *stream);
-/* dst <- src (replaces copy.deepcopy(model_state), tts_model.py:637-638); src batch 1 broadcasts */
+/* dst <- src (replaces copy.deepcopy(model_state), tts_model.py:637-638); src batch 1 broadcasts.
+ * The clone starts a new generation: its pending input latent is BOS (tts_model.py:748-753). */
 int ptts_lm_state_copy(ptts_lm_state *dst, const ptts_lm_state *src, void *stream);
 /* offsets of all rows to host (transformer.py:14 `.item()`; synchronises the stream) */
 int ptts_lm_state_offsets(ptts_lm_state *s, int32_t *h_offsets, void *stream);
@@ -83,6 +84,10 @@ int ptts_lm_prefill(ptts_engine *e, ptts_lm_state *s, const float *d_emb, int32_
 int ptts_lm_decode_step(ptts_engine *e, ptts_lm_state *s, const float *d_latent_in, const float *d_noise,
                         int32_t lsd_steps, float eos_threshold, float *d_latent_out, float *d_eos_logit,
                         uint8_t *d_is_eos, void *stream);
+/* Perf-run noise source: when d_noise is NULL and temp > 0 the step draws N(0, temp) itself from a
+ * counter-based device generator (the reference draws from torch's global CPU generator,
+ * flow_lm.py:131-135, which cannot be reproduced on device; parity runs pass d_noise or temp 0). */
+int ptts_lm_set_noise(ptts_lm_state *s, float temp, uint64_t seed);
 /* device pointer of the state's own copy of the latest latent f32[B, ldim] */
 const float *ptts_lm_latent_ptr(ptts_lm_state *s);
 
@@ -115,6 +120,11 @@ int ptts_timer_stop_ms(ptts_engine *e, void *stream, float *h_ms);
  * d_out (capacity in floats).  Names: see DESIGN.md.  Returns rows*cols or <0. */
 int64_t ptts_debug_read(ptts_engine *e, void *state, int32_t is_mimi, const char *name, float *d_out,
                         int64_t capacity, int32_t *rows, int32_t *cols, void *stream);
+/* Per-launch profiler (HIP events around every kernel launch on its own stream, tagged with call site,
+ * kernel and algorithmic bytes / flops).  stop() writes text lines "site kernel count total_ms bytes flops"
+ * to h_out and returns the length.  Never active inside a captured graph. */
+int ptts_profile_start(ptts_engine *e);
+int64_t ptts_profile_stop(ptts_engine *e, char *h_out, int64_t capacity);
 /* Packed weight bytes streamed by one LM decode step / one Mimi frame (roofline accounting) */
 int64_t ptts_lm_weight_bytes(ptts_engine *e);
 int64_t ptts_mimi_weight_bytes(ptts_engine *e);

@@ -50,6 +50,9 @@ PROTOTYPES = {
     "ptts_lm_prefill": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
     "ptts_lm_decode_step": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_float, _P, _P, _P, _P]),
     "ptts_lm_latent_ptr": (_P, [_P]),
+    "ptts_lm_set_noise": (C.c_int, [_P, C.c_float, C.c_uint64]),
+    "ptts_profile_start": (C.c_int, [_P]),
+    "ptts_profile_stop": (C.c_int64, [_P, C.c_char_p, C.c_int64]),
     "ptts_mimi_state_create": (C.c_int, [_P, C.c_int32, C.POINTER(_P)]),
     "ptts_mimi_state_destroy": (None, [_P]),
     "ptts_mimi_state_reset": (C.c_int, [_P, _P]),
@@ -97,6 +100,10 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  The MI355X hot path has no CPU fallback."
         )
+    # torch ships its own HIP runtime: import it first so that libptts binds to the SAME libamdhip64
+    # (two runtimes in one process do not share devices, streams or allocations)
+    import torch  # noqa: F401
+
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

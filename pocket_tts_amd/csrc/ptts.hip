@@ -3,6 +3,7 @@
 #include "ptts_kernels.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -30,6 +31,28 @@ static int fail(int code, const std::string &msg) {
   } while (0)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------------------------------------
+// Optional per-launch profiler: every kernel launch is bracketed by two HIP events on the stream it is
+// launched on and tagged with its call site, its kernel name and its ALGORITHMIC bytes / flops.
+// Off by default (and always off during graph capture); bench.py switches it on for a few eager steps.
+struct ProfRec { std::string site, kernel; double bytes, flops; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static thread_local const char *g_site = "";
+struct ProfScope {
+  hipStream_t st; bool on; size_t idx;
+  ProfScope(hipStream_t st_, const std::string &kernel, double bytes, double flops) : st(st_), on(g_prof_on), idx(0) {
+    if (!on) return;
+    ProfRec r{g_site, kernel, bytes, flops, nullptr, nullptr};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(r.a, st);
+    idx = g_prof.size();
+    g_prof.push_back(r);
+  }
+  ~ProfScope() { if (on) (void)hipEventRecord(g_prof[idx].b, st); }
+};
+#define SITE(x) g_site = (x)
 
 // ------------------------------------------------------------------------------------------------
 struct Lin {  // one packed weight matrix
@@ -89,6 +112,10 @@ struct ptts_lm_state {
   float *lat, *lat_prev;  // plain [B][ldim]
   float *eos_logit;
   uint8_t *is_eos;
+  // device noise source for perf runs (d_noise == NULL and rng_std > 0): N(0, rng_std^2), counter-based
+  float rng_std = 0.f;
+  unsigned long long rng_seed = 0;
+  int *rng_ctr = nullptr;
   size_t kv_plane() const { return (size_t)B * e->cfg.num_heads * cap * 64; }
   float *K(int l) { return kv + (size_t)(2 * l) * kv_plane(); }
   float *V(int l) { return kv + (size_t)(2 * l + 1) * kv_plane(); }
@@ -248,13 +275,41 @@ static void launch_cfg(hipStream_t st, const GemmArgs &a, int pre) {
   }
 }
 
+// Tile selection.  K-split configs (TM row tiles per wave, 8 waves split K, LDS-reduced) give NT x ceil(MT/TM)
+// workgroups and stream each weight fragment ceil(MT/TM) times (L2 / Infinity Cache absorb the re-reads);
+// the 2-D tiled configs amortise operand loads over 2x4 tiles per wave but need a large grid to fill 256 CUs.
+// Pick the K-split row-tile count TM that still yields >= ~256 workgroups, and use 2-D tiles only when
+// their grid is large.
+static int pick_cfg(const GemmArgs &a) {
+  const long tiled = (long)cdiv(a.NT, 4) * cdiv(a.MT, 8);
+  if (a.MT > 4 && tiled >= 192) return a.NT >= 4 ? 3 : a.NT >= 2 ? 4 : 5;
+  if (a.MT > 64) {  // K-split would re-stream weights too often
+    if (tiled < 192) return 6;  // small problem, many rows: one tile per wave for the largest grid
+    return a.NT >= 4 ? 3 : a.NT >= 2 ? 4 : 5;
+  }
+  int tm = a.MT >= 4 ? 4 : a.MT >= 2 ? 2 : 1;
+  while (tm > 1 && (long)a.NT * cdiv(a.MT, tm) < 256) tm >>= 1;
+  return tm == 4 ? 2 : tm == 2 ? 1 : 0;
+}
+static const char *const kCfgName[7] = {"gemm<1,1,8,1,1>", "gemm<1,2,8,1,1>", "gemm<1,4,8,1,1>", "gemm<2,4,1,2,2>",
+                                        "gemm<2,4,1,1,4>", "gemm<1,4,1,1,4>", "gemm<1,1,1,1,4>"};
+
 static void launch_gemm(hipStream_t st, const GemmArgs &a, int pre) {
-  if (a.MT <= 1) launch_cfg<1, 1, 8, 1, 1>(st, a, pre);
-  else if (a.MT == 2) launch_cfg<1, 2, 8, 1, 1>(st, a, pre);
-  else if (a.MT <= 4) launch_cfg<1, 4, 8, 1, 1>(st, a, pre);
-  else if (a.NT >= 4) launch_cfg<2, 4, 1, 2, 2>(st, a, pre);
-  else if (a.NT >= 2) launch_cfg<2, 4, 1, 1, 4>(st, a, pre);
-  else launch_cfg<1, 4, 1, 1, 4>(st, a, pre);
+  // algorithmic traffic: weights once + input rows once (x taps re-read from cache, not counted) + output
+  const double K = (double)a.KF * 16, N = (double)a.NT * 16, M = (double)a.M;
+  double bytes = 4.0 * (N * K + M * (double)a.CF * 16 + M * N);
+  if (a.epi == EPI_RES || a.epi == EPI_GATE) bytes += 4.0 * M * N;
+  const int cfg = pick_cfg(a);
+  ProfScope ps(st, std::string(kCfgName[cfg]) + (pre == PRE_NONE ? "" : pre == PRE_ELU ? "+elu" : "+addsilu"), bytes, 2.0 * M * N * K);
+  switch (cfg) {
+    case 0: launch_cfg<1, 1, 8, 1, 1>(st, a, pre); break;
+    case 1: launch_cfg<1, 2, 8, 1, 1>(st, a, pre); break;
+    case 2: launch_cfg<1, 4, 8, 1, 1>(st, a, pre); break;
+    case 3: launch_cfg<2, 4, 1, 2, 2>(st, a, pre); break;
+    case 4: launch_cfg<2, 4, 1, 1, 4>(st, a, pre); break;
+    case 5: launch_cfg<1, 4, 1, 1, 4>(st, a, pre); break;
+    default: launch_cfg<1, 1, 1, 1, 4>(st, a, pre); break;
+  }
 }
 
 static GemmArgs mk_gemm(const Lin &L, const float *X, int XF, int MT, int M) {
@@ -282,6 +337,7 @@ static void launch_ln(hipStream_t st, const float *X, long xds, int XF, float *Y
   LnArgs a;
   a.X = X; a.Xdstride = xds; a.XF = XF; a.Y = Y; a.YF = YF; a.w = w; a.b = b;
   a.shift = shift; a.scale = scale; a.SF = SF; a.KF = KF; a.eps = eps; a.par = par;
+  ProfScope ps(st, "layernorm", 8.0 * MT * 16 * KF * 16, 0);
   layernorm_kernel<<<MT, 256, 0, st>>>(a);
 }
 
@@ -302,11 +358,17 @@ struct TrCtx {
   float *Kc, *Vc;
   const int *offset;
   const float *freq;
+  double kv_keys;  // sum over sequences of the keys attended (profiling only)
+  const char *tag;
 };
 
 static void run_tr_layer(hipStream_t st, const TrLayer &T, const TrCtx &c) {
   const int DF = c.D / 16;
+  const std::string tg(c.tag);
+  std::string s1 = tg + ".ln1", s2 = tg + ".qkv", s3 = tg + ".attn", s4 = tg + ".out", s5 = tg + ".ln2", s6 = tg + ".ff1", s7 = tg + ".ff2";
+  SITE(s1.c_str());
   launch_ln(st, c.x_in, 0, DF, c.h, DF, T.ln1_w, T.ln1_b, nullptr, nullptr, 0, DF, 1e-5f, c.MT, nullptr);
+  SITE(s2.c_str());
   GemmArgs a = mk_gemm(T.qkv, c.h, DF, c.MT, c.M);
   a.epi = EPI_QKV;
   a.Q = c.q; a.Kc = c.Kc; a.Vc = c.Vc; a.offset = c.offset; a.freq = c.freq;
@@ -316,18 +378,31 @@ static void run_tr_layer(hipStream_t st, const TrLayer &T, const TrCtx &c) {
   at.Q = c.q; at.Kc = c.Kc; at.Vc = c.Vc; at.offset = c.offset; at.H = c.H; at.Tq = c.Tq; at.QB = c.QB;
   at.cap = c.cap; at.ring = c.ring; at.ctx = c.ctx; at.splits = c.splits; at.part = c.part; at.Y = c.ao; at.YF = DF;
   const int BH = (c.M / c.Tq) * c.H;
-  attn_kernel<<<dim3(BH, c.QB, c.splits), 64, 0, st>>>(at);
-  if (c.splits > 1) attn_combine_kernel<<<dim3(BH, c.QB), 256, 0, st>>>(at);
+  SITE(s3.c_str());
+  {
+    // K and V rows of every attended key once per head + q in + o out
+    ProfScope ps(st, "attn", c.kv_keys * c.H * 64 * 4 * 2 + 8.0 * c.M * c.D, 4.0 * c.kv_keys * c.H * 64 * std::min(c.Tq, 16));
+    attn_kernel<<<dim3(BH, c.QB, c.splits), 64, 0, st>>>(at);
+  }
+  if (c.splits > 1) {
+    ProfScope ps(st, "attn_combine", (double)BH * c.QB * c.splits * 16 * ATT_PSTRIDE * 4, 0);
+    attn_combine_kernel<<<dim3(BH, c.QB), 256, 0, st>>>(at);
+  }
+  SITE(s4.c_str());
   a = mk_gemm(T.out, c.ao, DF, c.MT, c.M);
   a.epi = EPI_RES; a.R = c.x_in; a.RF = DF; a.Y = c.x; a.YF = DF; a.ls = T.ls1;
   launch_gemm(st, a, PRE_NONE);
+  SITE(s5.c_str());
   launch_ln(st, c.x, 0, DF, c.h, DF, T.ln2_w, T.ln2_b, nullptr, nullptr, 0, DF, 1e-5f, c.MT, nullptr);
+  SITE(s6.c_str());
   a = mk_gemm(T.ff1, c.h, DF, c.MT, c.M);
   a.epi = EPI_STORE; a.act = ACT_GELU; a.Y = c.ff; a.YF = c.FF / 16;
   launch_gemm(st, a, PRE_NONE);
+  SITE(s7.c_str());
   a = mk_gemm(T.ff2, c.ff, c.FF / 16, c.MT, c.M);
   a.epi = EPI_RES; a.R = c.x; a.RF = DF; a.Y = c.x_out; a.YF = DF; a.Ydstride = c.out_ds; a.par = c.par; a.ls = T.ls2;
   launch_gemm(st, a, PRE_NONE);
+  SITE("");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -533,6 +608,7 @@ extern "C" int ptts_lm_state_create(ptts_engine *e, int32_t B, int32_t t_cap, pt
   CHK(dallocT(nullptr, &s->lat_prev, (size_t)B * c.ldim));
   CHK(dallocT(nullptr, &s->eos_logit, B));
   CHK(dallocT(nullptr, &s->is_eos, B));
+  CHK(dallocT(nullptr, &s->rng_ctr, 1));
   fill_kernel<<<cdiv(B * c.ldim, 256), 256, 0, e->stream>>>(s->lat_prev, (long)B * c.ldim, NAN);
   HIPCHK(hipStreamSynchronize(e->stream));
   *out = s;
@@ -547,7 +623,7 @@ extern "C" void ptts_lm_state_destroy(ptts_lm_state *s) {
   free_scratch(&s->dec);
   if (s->pre.x) free_scratch(&s->pre);
   hipFree(s->xlat); hipFree(s->latfm); hipFree(s->c); hipFree(s->ce); hipFree(s->mod); hipFree(s->fx);
-  hipFree(s->fh); hipFree(s->f1); hipFree(s->lat); hipFree(s->lat_prev); hipFree(s->eos_logit); hipFree(s->is_eos);
+  hipFree(s->fh); hipFree(s->f1); hipFree(s->lat); hipFree(s->lat_prev); hipFree(s->eos_logit); hipFree(s->is_eos); hipFree(s->rng_ctr);
   delete s;
 }
 
@@ -612,8 +688,15 @@ extern "C" int ptts_lm_state_copy(ptts_lm_state *dst, const ptts_lm_state *src, 
         }
   }
   for (int b = 0; b < dst->B; ++b) dst->h_off[b] = src->h_off[src->B == 1 ? 0 : b];
-  HIPCHK(hipMemcpyAsync(dst->offset, dst->h_off.data(), dst->B * sizeof(int), hipMemcpyHostToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));  // h_off.data() is pageable host memory
+  if (*std::min_element(dst->h_off.begin(), dst->h_off.end()) == T) {
+    set_int_kernel<<<cdiv(dst->B, 256), 256, 0, st>>>(dst->offset, dst->B, T);
+  } else {
+    HIPCHK(hipMemcpyAsync(dst->offset, dst->h_off.data(), dst->B * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));  // h_off.data() is pageable host memory
+  }
+  // a cloned state starts a new generation: next input is BOS (NaN), reference tts_model.py:748-753
+  fill_kernel<<<cdiv(dst->B * c.ldim, 256), 256, 0, st>>>(dst->lat_prev, (long)dst->B * c.ldim, NAN);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 
@@ -626,6 +709,50 @@ extern "C" int ptts_lm_state_offsets(ptts_lm_state *s, int32_t *h, void *stream)
 
 extern "C" const float *ptts_lm_latent_ptr(ptts_lm_state *s) { return s->lat_prev; }
 
+extern "C" int ptts_lm_set_noise(ptts_lm_state *s, float temp, uint64_t seed) {
+  if (temp < 0) return fail(-1, "temperature must be >= 0");
+  s->rng_std = std::sqrt(temp);  // std = temp ** 0.5 (reference flow_lm.py:132)
+  s->rng_seed = seed;
+  return 0;
+}
+
+extern "C" int ptts_profile_start(ptts_engine *e) {
+  (void)e;
+  for (auto &r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  g_prof.clear();
+  g_prof_on = true;
+  return 0;
+}
+
+// Stops profiling and writes one line per (site, kernel): "site kernel count total_ms bytes flops\n"
+extern "C" int64_t ptts_profile_stop(ptts_engine *e, char *h_out, int64_t capacity) {
+  g_prof_on = false;
+  if (hipDeviceSynchronize() != hipSuccess) return fail(-2, "sync failed");
+  std::map<std::pair<std::string, std::string>, std::array<double, 4>> agg;
+  std::vector<std::pair<std::string, std::string>> order;
+  for (auto &r : g_prof) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.a, r.b);
+    auto key = std::make_pair(r.site, r.kernel);
+    if (!agg.count(key)) { agg[key] = {0, 0, 0, 0}; order.push_back(key); }
+    auto &v = agg[key];
+    v[0] += 1; v[1] += ms; v[2] += r.bytes; v[3] += r.flops;
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+  std::string out;
+  char line[512];
+  for (auto &k : order) {
+    auto &v = agg[k];
+    snprintf(line, sizeof line, "%s %s %.0f %.6f %.0f %.0f\n", k.first.empty() ? "-" : k.first.c_str(), k.second.c_str(), v[0], v[1], v[2], v[3]);
+    out += line;
+  }
+  (void)e;
+  if ((int64_t)out.size() + 1 > capacity) return fail(-1, "profile buffer too small");
+  memcpy(h_out, out.c_str(), out.size() + 1);
+  return (int64_t)out.size();
+}
+
 static void lm_layers(hipStream_t st, ptts_engine *e, ptts_lm_state *s, Scratch &sc, int M, int Tq) {
   const ptts_config &c = e->cfg;
   for (int l = 0; l < c.num_layers; ++l) {
@@ -636,6 +763,9 @@ static void lm_layers(hipStream_t st, ptts_engine *e, ptts_lm_state *s, Scratch 
     t.x_in = sc.x; t.x = sc.x; t.x_out = sc.x; t.out_ds = 0; t.par = nullptr;
     t.h = sc.h; t.ao = sc.ao; t.ff = sc.ff; t.q = sc.q; t.part = sc.part;
     t.Kc = s->K(l); t.Vc = s->V(l); t.offset = s->offset; t.freq = e->freq_lm;
+    t.kv_keys = 0;
+    for (int b = 0; b < s->B; ++b) t.kv_keys += s->h_off[b] + Tq;
+    t.tag = "lm";
     run_tr_layer(st, e->lm[l], t);
   }
 }
@@ -673,13 +803,21 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
   const int B = s->B, MT = s->MT, D = c.d_model, FD = c.flow_dim, DF = D / 16, FDF = FD / 16, LF = c.ldim / 16;
   Scratch &sc = s->dec;
   const float *tcomb = e->tcomb[lsd_steps];
-  prep_lm_kernel<<<cdiv(MT * LF * 64, 256), 256, 0, st>>>(d_latent_in ? d_latent_in : s->lat_prev, e->bos, d_noise,
-                                                           s->xlat, s->lat, s->latfm, B, c.ldim, MT);
+  SITE("lm.prep");
+  {
+    ProfScope ps(st, "prep_lm", 16.0 * B * c.ldim, 0);
+    prep_lm_kernel<<<cdiv(MT * LF * 64, 256), 256, 0, st>>>(d_latent_in ? d_latent_in : s->lat_prev, e->bos, d_noise,
+                                                             s->xlat, s->lat, s->latfm, B, c.ldim, MT, s->rng_std,
+                                                             s->rng_seed, s->rng_ctr);
+  }
+  SITE("lm.in_linear");
   GemmArgs a = mk_gemm(e->in_linear, s->xlat, LF, MT, B);
   a.Y = sc.x; a.YF = DF;
   launch_gemm(st, a, PRE_NONE);
   lm_layers(st, e, s, sc, B, 1);
+  SITE("lm.out_norm");
   launch_ln(st, sc.x, 0, DF, s->c, DF, e->outnorm_w, e->outnorm_b, nullptr, nullptr, 0, DF, 1e-5f, MT, nullptr);
+  SITE("flow.head");
   a = mk_gemm(e->head, s->c, DF, MT, B);
   a.epi = EPI_HEAD; a.Y = s->ce; a.YF = FDF; a.head_nt = FDF; a.eos_thr = eos_thr;
   a.eos_logit = s->eos_logit; a.is_eos = s->is_eos;
@@ -687,9 +825,11 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
   const int AF = e->adaln.NT;
   for (int i = 0; i < lsd_steps; ++i) {
     // all AdaLN modulations of the step in one GEMM on silu(t_emb + cond)  (mlp.py:107,127,210)
+    SITE("flow.adaln");
     a = mk_gemm(e->adaln, s->ce, FDF, MT, B);
     a.prevec = tcomb + (size_t)i * FD; a.Y = s->mod; a.YF = AF;
     launch_gemm(st, a, PRE_ADDSILU);
+    SITE("flow.input_proj");
     a = mk_gemm(e->input_proj, s->latfm, LF, MT, B);
     a.Y = s->fx; a.YF = FDF;
     launch_gemm(st, a, PRE_NONE);
@@ -697,22 +837,33 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
       const float *shift = s->mod + (size_t)(r * 3 * FDF) * 256;
       const float *scale = shift + (size_t)FDF * 256;
       const float *gate = scale + (size_t)FDF * 256;
+      SITE("flow.res.ln");
       launch_ln(st, s->fx, 0, FDF, s->fh, FDF, e->res[r].ln_w, e->res[r].ln_b, shift, scale, AF, FDF, 1e-6f, MT, nullptr);
+      SITE("flow.res.l0");
       a = mk_gemm(e->res[r].l0, s->fh, FDF, MT, B);
       a.act = ACT_SILU; a.Y = s->f1; a.YF = FDF;
       launch_gemm(st, a, PRE_NONE);
+      SITE("flow.res.l2");
       a = mk_gemm(e->res[r].l2, s->f1, FDF, MT, B);
       a.epi = EPI_GATE; a.R = s->fx; a.RF = FDF; a.G = gate; a.GF = AF; a.Y = s->fx; a.YF = FDF;
       launch_gemm(st, a, PRE_NONE);
     }
     const float *shift = s->mod + (size_t)(c.flow_depth * 3 * FDF) * 256;
     const float *scale = shift + (size_t)FDF * 256;
+    SITE("flow.final.ln");
     launch_ln(st, s->fx, 0, FDF, s->fh, FDF, nullptr, nullptr, shift, scale, AF, FDF, 1e-6f, MT, nullptr);
+    SITE("flow.final");
     a = mk_gemm(e->fin, s->fh, FDF, MT, B);
     a.epi = EPI_LATENT; a.lat = s->lat; a.ldim = c.ldim; a.inv_steps = 1.0f / (float)lsd_steps; a.Y = s->latfm; a.YF = LF;
     launch_gemm(st, a, PRE_NONE);
   }
-  add_int_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->offset, B, 1);
+  SITE("lm.tail");
+  {
+    ProfScope ps(st, "step_tail", 8.0 * B * c.ldim, 0);
+    add_int_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->offset, B, 1);
+    add_int_kernel<<<1, 64, 0, st>>>(s->rng_ctr, 1, 1);
+  }
+  SITE("");
   hipMemcpyAsync(s->lat_prev, s->lat, (size_t)B * c.ldim * sizeof(float), hipMemcpyDeviceToDevice, st);
   if (d_latent_out) hipMemcpyAsync(d_latent_out, s->lat, (size_t)B * c.ldim * sizeof(float), hipMemcpyDeviceToDevice, st);
   if (d_eos_logit) hipMemcpyAsync(d_eos_logit, s->eos_logit, B * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -816,12 +967,21 @@ extern "C" int ptts_mimi_state_reset(ptts_mimi_state *s, void *stream) {
 static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, const float *d_latent, float *d_pcm) {
   const ptts_config &c = e->cfg;
   const int B = s->B, C = c.m_dim, CF = C / 16, LF = c.ldim / 16, st16 = c.upsample_stride;
-  prep_mimi_kernel<<<cdiv(s->MTb * LF * 64, 256), 256, 0, st>>>(d_latent, e->emb_std, e->emb_mean, s->zl, B, c.ldim, s->MTb);
+  SITE("mimi.prep");
+  {
+    ProfScope ps(st, "prep_mimi", 8.0 * B * c.ldim, 0);
+    prep_mimi_kernel<<<cdiv(s->MTb * LF * 64, 256), 256, 0, st>>>(d_latent, e->emb_std, e->emb_mean, s->zl, B, c.ldim, s->MTb);
+  }
+  SITE("mimi.quant");
   GemmArgs a = mk_gemm(e->quant, s->zl, LF, s->MTb, B);
   a.Y = s->zq; a.Ydstride = s->zq_stride; a.YF = CF; a.par = s->frame;
   launch_gemm(st, a, PRE_NONE);
   long tot = (long)B * st16 * (C / 4);
-  upsample_kernel<<<cdiv(tot, 256), 256, 0, st>>>(s->zq, s->zq_stride, s->frame, e->up_w, s->u0, B, C, st16);
+  SITE("mimi.upsample");
+  {
+    ProfScope ps(st, "upsample", 4.0 * B * C * (2 + st16), 0);
+    upsample_kernel<<<cdiv(tot, 256), 256, 0, st>>>(s->zq, s->zq_stride, s->frame, e->up_w, s->u0, B, C, st16);
+  }
   const int M16 = B * st16;
   for (int l = 0; l < c.m_layers; ++l) {
     TrCtx t;
@@ -832,10 +992,13 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
     t.x_out = last ? s->tr_out : s->u; t.out_ds = last ? s->tr_stride : 0; t.par = last ? s->frame : nullptr;
     t.h = s->h; t.ao = s->ao; t.ff = s->ff; t.q = s->q; t.part = s->part;
     t.Kc = s->K(l); t.Vc = s->V(l); t.offset = s->offset; t.freq = e->freq_mimi;
+    t.kv_keys = (double)B * std::min(e->ring, (s->h_frame + 1) * st16);
+    t.tag = "mimi";
     run_tr_layer(st, e->mm[l], t);
   }
   // SEANet decoder (seanet.py:141-180) as implicit GEMMs over (sequence, time) rows
   int mult = 8;
+  SITE("seanet.conv0");
   a = mk_gemm(e->conv0, s->tr_out, CF, s->MT16, M16);
   a.Xdstride = s->tr_stride; a.T = s->rows[0]; a.par = s->frame;
   a.Y = s->a0; a.Ydstride = s->a0_stride; a.YF = mult * c.n_filters / 16;
@@ -846,15 +1009,21 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
     const int cin = mult * c.n_filters, cout = cin / 2, hid = cout / c.compress;
     const int Tin = s->rows[i], Tout = s->rows[i + 1];
     const int MTin = B * Tin / 16, MTout = B * Tout / 16;
+    static const char *sn[3][3] = {{"seanet.convtr1", "seanet.res1a", "seanet.res1b"},
+                                   {"seanet.convtr2", "seanet.res2a", "seanet.res2b"},
+                                   {"seanet.convtr3", "seanet.res3a", "seanet.res3b"}};
+    SITE(sn[i][0]);
     a = mk_gemm(e->convtr[i], xin, cin / 16, MTin, B * Tin);
     a.Xdstride = xds; a.T = Tin; a.par = s->frame;
     a.epi = EPI_CONVTR; a.cout = cout; a.stride = c.ratios[i];
     a.Y = s->cbuf[i]; a.Ydstride = s->c_stride[i]; a.YF = cout / 16;
     launch_gemm(st, a, PRE_ELU);
+    SITE(sn[i][1]);
     a = mk_gemm(e->res_a[i], s->cbuf[i], cout / 16, MTout, B * Tout);
     a.Xdstride = s->c_stride[i]; a.T = Tout; a.par = s->frame;
     a.Y = s->rbuf[i]; a.YF = hid / 16;
     launch_gemm(st, a, PRE_ELU);
+    SITE(sn[i][2]);
     a = mk_gemm(e->res_b[i], s->rbuf[i], hid / 16, MTout, B * Tout);
     a.T = Tout; a.par = s->frame;
     a.epi = EPI_RES; a.R = s->cbuf[i]; a.Rdstride = s->c_stride[i]; a.RF = cout / 16;
@@ -865,12 +1034,18 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
     mult /= 2;
   }
   const int Tl = s->rows[3];
+  SITE("seanet.conv_last");
   a = mk_gemm(e->conv_last, xin, c.n_filters / 16, B * Tl / 16, B * Tl);
   a.Xdstride = xds; a.T = Tl; a.par = s->frame;
   a.epi = EPI_PCM; a.pcm = d_pcm ? d_pcm : s->pcm_dbg;
   launch_gemm(st, a, PRE_ELU);
-  add_int_kernel<<<1, 64, 0, st>>>(s->frame, 1, 1);
-  add_int_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->offset, B, st16);
+  SITE("mimi.tail");
+  {
+    ProfScope ps(st, "step_tail", 8.0 * B, 0);
+    add_int_kernel<<<1, 64, 0, st>>>(s->frame, 1, 1);
+    add_int_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->offset, B, st16);
+  }
+  SITE("");
   return 0;
 }
 

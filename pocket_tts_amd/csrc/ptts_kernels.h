@@ -379,8 +379,22 @@ __global__ void from_fm_kernel(const float *src, float *dst, int M, int K, int F
 
 // FlowLM step input: latent (external or the previous output; NaN = BOS -> bos_emb, reference
 // flow_lm.py:121) to FM; LSD start point: noise (or zeros) to the plain `lat` buffer and its FM copy.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// N(0,1) from a counter (Box-Muller on two 24-bit uniforms of a splitmix64 hash): perf-run noise source
+__device__ __forceinline__ float counter_normal(unsigned long long seed, unsigned ctr, unsigned idx) {
+  unsigned long long z = mix64(seed + 0x9E3779B97F4A7C15ull * (((unsigned long long)ctr << 32) | idx));
+  float u1 = ((float)((z >> 40) & 0xFFFFFF) + 1.0f) * (1.0f / 16777216.0f);
+  float u2 = (float)((z >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
 __global__ void prep_lm_kernel(const float *lat_in, const float *bos, const float *noise, float *x_fm, float *lat,
-                               float *lat_fm, int B, int ldim, int MT) {
+                               float *lat_fm, int B, int ldim, int MT, float rng_std, unsigned long long rng_seed,
+                               const int *rng_ctr) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int KF = ldim / 16;
   if (i >= MT * KF * 64) return;
@@ -397,7 +411,15 @@ __global__ void prep_lm_kernel(const float *lat_in, const float *bos, const floa
     v.y = v.y != v.y ? b.y : v.y;
     v.z = v.z != v.z ? b.z : v.z;
     v.w = v.w != v.w ? b.w : v.w;
-    if (noise) z = *(const f32x4 *)(noise + (size_t)m * ldim + k);
+    if (noise) {
+      z = *(const f32x4 *)(noise + (size_t)m * ldim + k);
+    } else if (rng_std > 0.f) {
+      const unsigned ctr = (unsigned)*rng_ctr, base = (unsigned)(m * ldim + k);
+      z.x = rng_std * counter_normal(rng_seed, ctr, base + 0);
+      z.y = rng_std * counter_normal(rng_seed, ctr, base + 1);
+      z.z = rng_std * counter_normal(rng_seed, ctr, base + 2);
+      z.w = rng_std * counter_normal(rng_seed, ctr, base + 3);
+    }
   }
   *(f32x4 *)(x_fm + (size_t)i * 4) = v;
   *(f32x4 *)(lat_fm + (size_t)i * 4) = z;
@@ -488,14 +510,29 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   const float *X = a.X + par * a.Xdstride;
   const int k0 = (a.KF * wave) / 4, k1 = (a.KF * (wave + 1)) / 4;
   f32x4 v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int kf = k0 + i;
+    if (kf < k1) v[i] = *(const f32x4 *)(X + (((size_t)mt * a.XF + kf) * 64 + lane) * 4);
+  }
+  // the gains / biases are cold in cache once per step: issue their loads together with the data
+  f32x4 wv[16], bv[16];
+  if (a.w) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int kf = k0 + i;
+      if (kf < k1) {
+        const int k = 16 * kf + 4 * (lane >> 4);
+        wv[i] = *(const f32x4 *)(a.w + k);
+        bv[i] = *(const f32x4 *)(a.b + k);
+      }
+    }
+  }
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     int kf = k0 + i;
-    if (kf < k1) {
-      v[i] = *(const f32x4 *)(X + (((size_t)mt * a.XF + kf) * 64 + lane) * 4);
-      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    }
+    if (kf < k1) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
   __shared__ float red[2][4][16];
   s += __shfl_xor(s, 16);
@@ -525,8 +562,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
     int kf = k0 + i;
     if (kf < k1) {
       f32x4 y = (v[i] - mean) * rstd;
-      const int k = 16 * kf + 4 * (lane >> 4);
-      if (a.w) y = y * *(const f32x4 *)(a.w + k) + *(const f32x4 *)(a.b + k);
+      if (a.w) y = y * wv[i] + bv[i];
       if (a.scale) {
         f32x4 sc = *(const f32x4 *)(a.scale + (((size_t)mt * a.SF + kf) * 64 + lane) * 4);
         f32x4 sh = *(const f32x4 *)(a.shift + (((size_t)mt * a.SF + kf) * 64 + lane) * 4);

@@ -63,29 +63,33 @@ class LMState:
             self.handle = None
 
     def reset(self):
-        _lib.check(self.engine.lib.ptts_lm_state_reset(self.handle, None))
+        _lib.check(self.engine.lib.ptts_lm_state_reset(self.handle, self.engine._sp))
+
+    def set_noise(self, temp: float, seed: int = 0):
+        """device-side N(0, temp) noise for steps called with noise=None (perf runs)"""
+        _lib.check(self.engine.lib.ptts_lm_set_noise(self.handle, float(temp), int(seed)))
 
     def offsets(self) -> np.ndarray:
         out = (C.c_int32 * self.batch)()
-        _lib.check(self.engine.lib.ptts_lm_state_offsets(self.handle, out, None))
+        _lib.check(self.engine.lib.ptts_lm_state_offsets(self.handle, out, self.engine._sp))
         return np.array(out[:], dtype=np.int64)
 
     def import_layer(self, layer: int, cache: torch.Tensor, t: int):
         """cache: f32[2, Bsrc, >=t, H, 64] in the reference layout (reference transformer.py:32-36)."""
         cache = cache[:, :, :t].to(self.engine.device, torch.float32).contiguous()
         self.engine._pre()
-        _lib.check(self.engine.lib.ptts_lm_state_import(self.handle, layer, _ptr(cache), cache.shape[1], t, None))
+        _lib.check(self.engine.lib.ptts_lm_state_import(self.handle, layer, _ptr(cache), cache.shape[1], t, self.engine._sp))
         self.engine.sync()
 
     def export_layer(self, layer: int, t: int) -> torch.Tensor:
         e = self.engine
         out = torch.empty((2, self.batch, t, e.H, 64), dtype=torch.float32, device=e.device)
-        _lib.check(e.lib.ptts_lm_state_export(self.handle, layer, _ptr(out), t, None))
+        _lib.check(e.lib.ptts_lm_state_export(self.handle, layer, _ptr(out), t, e._sp))
         e.sync()
         return out
 
     def copy_from(self, src: "LMState"):
-        _lib.check(self.engine.lib.ptts_lm_state_copy(self.handle, src.handle, None))
+        _lib.check(self.engine.lib.ptts_lm_state_copy(self.handle, src.handle, self.engine._sp))
 
     def __del__(self):
         try:
@@ -108,7 +112,7 @@ class MimiState:
             self.handle = None
 
     def reset(self):
-        _lib.check(self.engine.lib.ptts_mimi_state_reset(self.handle, None))
+        _lib.check(self.engine.lib.ptts_mimi_state_reset(self.handle, self.engine._sp))
 
     def __del__(self):
         try:
@@ -150,8 +154,10 @@ class Engine:
         _lib.check(self.lib.ptts_create(C.byref(pc), arr, len(spec), self.device.index or 0, C.byref(h)))
         self.handle = h
         del keep
-        # the library's stream, visible to torch so that tensor ops can be ordered against it
-        self.stream = torch.cuda.ExternalStream(self.lib.ptts_engine_stream(h), device=self.device)
+        # All work is queued on a torch-owned stream passed through the ABI's `stream` argument, so torch's
+        # caching allocator (record_stream) and the library agree on one stream whose lifetime torch manages.
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._sp = C.c_void_p(self.stream.cuda_stream)
         t = cfg.flow_lm.transformer
         self.D, self.H, self.L = t.d_model, t.num_heads, t.num_layers
         self.ldim = cfg.mimi.quantizer.dimension
@@ -173,19 +179,34 @@ class Engine:
 
     # ---- utilities
     def sync(self):
-        _lib.check(self.lib.ptts_sync(self.handle, None))
+        _lib.check(self.lib.ptts_sync(self.handle, self._sp))
 
     @property
     def stream_ptr(self):
-        return self.lib.ptts_engine_stream(self.handle)
+        return self.stream.cuda_stream
 
     def timer_start(self):
-        _lib.check(self.lib.ptts_timer_start(self.handle, None))
+        _lib.check(self.lib.ptts_timer_start(self.handle, self._sp))
 
     def timer_stop_ms(self) -> float:
         ms = C.c_float()
-        _lib.check(self.lib.ptts_timer_stop_ms(self.handle, None, C.byref(ms)))
+        _lib.check(self.lib.ptts_timer_stop_ms(self.handle, self._sp, C.byref(ms)))
         return ms.value
+
+    def profile_start(self):
+        _lib.check(self.lib.ptts_profile_start(self.handle))
+
+    def profile_stop(self) -> list:
+        """-> [{site, kernel, count, total_ms, bytes, flops}] in launch order"""
+        buf = C.create_string_buffer(1 << 20)
+        n = self.lib.ptts_profile_stop(self.handle, buf, len(buf))
+        _lib.check(int(n))
+        rows = []
+        for line in buf.value.decode().splitlines():
+            site, kernel, cnt, ms, by, fl = line.split()
+            rows.append(dict(site=site, kernel=kernel, count=int(float(cnt)), total_ms=float(ms),
+                             bytes=float(by), flops=float(fl)))
+        return rows
 
     def lm_weight_bytes(self) -> int:
         return self.lib.ptts_lm_weight_bytes(self.handle)
@@ -210,7 +231,7 @@ class Engine:
         if emb.dim() != 3 or emb.shape[0] != state.batch or emb.shape[2] != self.D:
             raise ValueError(f"prefill expects [B={state.batch}, T, {self.D}], got {tuple(emb.shape)}")
         self._pre()
-        _lib.check(self.lib.ptts_lm_prefill(self.handle, state.handle, _ptr(emb), emb.shape[1], None))
+        _lib.check(self.lib.ptts_lm_prefill(self.handle, state.handle, _ptr(emb), emb.shape[1], self._sp))
         emb.record_stream(self.stream)
         self._post()
 
@@ -226,7 +247,7 @@ class Engine:
         self._pre()
         _lib.check(self.lib.ptts_lm_decode_step(
             self.handle, state.handle, _ptr(latent_in), _ptr(noise), lsd_steps, eos_threshold,
-            _ptr(out_latent), _ptr(out_logit), _ptr(out_eos), None))
+            _ptr(out_latent), _ptr(out_logit), _ptr(out_eos), self._sp))
         for t in (latent_in, noise, out_latent, out_logit, out_eos):
             if t is not None:
                 t.record_stream(self.stream)
@@ -251,7 +272,7 @@ class Engine:
         return g
 
     def graph_launch(self, g):
-        _lib.check(self.lib.ptts_graph_launch(g, None))
+        _lib.check(self.lib.ptts_graph_launch(g, self._sp))
 
     def graph_destroy(self, g):
         self.lib.ptts_graph_destroy(g)
@@ -263,7 +284,7 @@ class Engine:
         if out_pcm is None:
             out_pcm = torch.empty((B, self.frame_samples), dtype=torch.float32, device=self.device)
         self._pre()
-        _lib.check(self.lib.ptts_mimi_decode(self.handle, state.handle, _ptr(latent), _ptr(out_pcm), None))
+        _lib.check(self.lib.ptts_mimi_decode(self.handle, state.handle, _ptr(latent), _ptr(out_pcm), self._sp))
         latent.record_stream(self.stream)
         out_pcm.record_stream(self.stream)
         self._post()
@@ -276,7 +297,7 @@ class Engine:
         self._pre()
         r, c = C.c_int32(), C.c_int32()
         n = self.lib.ptts_debug_read(self.handle, state.handle, int(is_mimi), name.encode(), _ptr(buf), cap,
-                                     C.byref(r), C.byref(c), None)
+                                     C.byref(r), C.byref(c), self._sp)
         _lib.check(int(n))
         self.sync()
         return buf[: r.value * c.value].view(r.value, c.value).clone()
