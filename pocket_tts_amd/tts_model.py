@@ -1,0 +1,328 @@
+"""Drop-in `TTSModel` surface over the MI355X engine.
+
+Keeps the reference's public API (`pocket_tts/__init__.py:6-19`, `tts_model.py:232-242,477-552,788-790,
+1047-1052`): `TTSModel.load_model`, `.device`, `.sample_rate`, `get_state_for_audio_prompt`,
+`generate_audio`, `generate_audio_stream`, and `export_model_state`.  Voice states keep the reference
+format (dict module name -> {"cache": f32[2,1,T,H,64], "offset": i64[1]}, safetensors keys
+"<module>/<cache|offset>").  The two hot loops of the reference (`_autoregressive_generation`
+tts_model.py:744-779 and `_decode_audio_worker` :433-474) are replaced by hipGraph launches of the
+C-ABI engine; no worker threads are needed because the GPU queue provides the pipelining.
+"""
+
+from __future__ import annotations
+
+import logging
+import math
+import time
+from pathlib import Path
+
+import numpy as np
+import safetensors
+import safetensors.torch
+import torch
+
+from .config import CONFIGS_DIR, Config, load_config
+from .engine import Engine
+from .text import estimate_max_gen_len, prepare_text_prompt, split_into_best_sentences
+from .weights import generate_state_dict
+
+logger = logging.getLogger(__name__)
+
+DEFAULT_LANGUAGE = "english"
+DEFAULT_TEMPERATURE = 0.7
+DEFAULT_LSD_DECODE_STEPS = 1
+DEFAULT_NOISE_CLAMP = None
+DEFAULT_EOS_THRESHOLD = -4.0
+MAX_TOKEN_PER_CHUNK = 50
+
+PREDEFINED_VOICES = (
+    "cosette marius javert alba jean anna vera fantine charles paul eponine azelma george mary jane michael "
+    "eve bill_boerst peter_yearsley stuart_bell caro_davy giovanni lola juergen rafael estelle"
+).split()
+
+
+class SentencePieceTokenizer:
+    """Host-side tokenizer (reference conditioners/text.py:13-35); stays on the CPU."""
+
+    def __init__(self, n_bins: int, path: str):
+        import sentencepiece
+
+        if str(path).startswith(("hf://", "http://", "https://")):
+            raise FileNotFoundError(
+                f"tokenizer_path {path} needs a download; this build runs offline: point "
+                "flow_lm.lookup_table.tokenizer_path at a local sentencepiece model"
+            )
+        self.sp = sentencepiece.SentencePieceProcessor(str(path))
+        if n_bins != self.sp.vocab_size():
+            raise ValueError(f"sentencepiece tokenizer has vocab size={self.sp.vocab_size()} but nbins={n_bins}")
+
+    def encode(self, text: str) -> list:
+        return self.sp.encode(text, out_type=int)
+
+
+def _load_weights(cfg: Config, seed: int = 0) -> dict:
+    path = cfg.weights_path
+    if path is None:
+        logger.warning("No weights_path specified for FlowLM or TTSModel, model is uninitialized! "
+                       "(deterministic synthetic weights, seed %d)", seed)
+        return generate_state_dict(cfg, seed)
+    for p in (path, cfg.weights_path_without_voice_cloning):
+        if p and not str(p).startswith(("hf://", "http://", "https://")) and Path(p).exists():
+            return safetensors.torch.load_file(str(p))
+    raise FileNotFoundError(
+        f"weights_path {path} needs a download; this build runs offline: set weights_path to a local "
+        ".safetensors file (same keys as the reference checkpoint) or to null for synthetic weights"
+    )
+
+
+class TTSModel:
+    def __init__(self, engine: Engine, config: Config, tokenizer, temp, lsd_decode_steps, noise_clamp,
+                 eos_threshold, origin: Path | None = None):
+        self.engine = engine
+        self.config = config
+        self.tokenizer = tokenizer
+        self.temp = temp
+        self.lsd_decode_steps = lsd_decode_steps
+        self.noise_clamp = noise_clamp
+        self.eos_threshold = eos_threshold
+        self.origin = origin
+        self.has_voice_cloning = False  # the Mimi encoder path is not part of this build yet
+        self.pad_with_spaces_for_short_inputs = config.pad_with_spaces_for_short_inputs
+        self.model_recommended_frames_after_eos = config.model_recommended_frames_after_eos
+        self.remove_semicolons = config.remove_semicolons
+
+    # ---- reference properties (tts_model.py:92-98)
+    @property
+    def device(self) -> torch.device:
+        return self.engine.device
+
+    @property
+    def sample_rate(self) -> int:
+        return self.config.mimi.sample_rate
+
+    @classmethod
+    def load_model(cls, language: str | None = None, config: str | Path | None = None,
+                   temp: float | int = DEFAULT_TEMPERATURE, lsd_decode_steps: int = DEFAULT_LSD_DECODE_STEPS,
+                   noise_clamp: float | int | None = DEFAULT_NOISE_CLAMP, eos_threshold: float = DEFAULT_EOS_THRESHOLD,
+                   quantize: bool = False, device: str = "cuda:0", tokenizer=None):
+        """Same arguments and errors as the reference (tts_model.py:232-315) plus `device`."""
+        if config is not None and language is not None:
+            raise ValueError("Cannot specify both config and language, please choose one or the other.")
+        if config is None and language is None:
+            language = DEFAULT_LANGUAGE
+        if language is not None:
+            if language == "french":
+                raise ValueError("For technical reasons, only a larger 24-layer model is available for French. "
+                                 "Please use the 'french_24l' language instead.")
+            config = CONFIGS_DIR / f"{language}.yaml"
+        config = Path(config)
+        if config.suffix not in (".yaml", ".yml"):
+            raise ValueError("Config should be a path to a YAML file ending with .yaml")
+        cfg = load_config(config)
+        if quantize:
+            logger.warning("quantize=True: the int8 weight path is not built yet; running the fp32 path")
+        weights = _load_weights(cfg)
+        if tokenizer is None:
+            tp = str(cfg.flow_lm.lookup_table.tokenizer_path)
+            if not tp.startswith(("hf://", "http://", "https://")) and not Path(tp).exists() and (config.parent / tp).exists():
+                tp = str(config.parent / tp)  # relative to the YAML file
+            tokenizer = SentencePieceTokenizer(cfg.flow_lm.lookup_table.n_bins, tp)
+        engine = Engine(cfg, weights, device)
+        return cls(engine, cfg, tokenizer, temp, lsd_decode_steps, noise_clamp, eos_threshold, origin=config)
+
+    # ---- voice state ------------------------------------------------------------------------
+    def get_state_for_audio_prompt(self, audio_conditioning, truncate: bool = False) -> dict:
+        """`.safetensors` voice states load exactly as in the reference (tts_model.py:846-851,1055-1072).
+        Encoding a waveform needs the Mimi encoder, which this build does not
+        contain yet; pre-computed conditioning can be passed to `get_state_for_conditioning`."""
+        if isinstance(audio_conditioning, (str, Path)) and str(audio_conditioning).endswith(".safetensors"):
+            if str(audio_conditioning).startswith(("hf://", "http://", "https://")):
+                raise FileNotFoundError(f"{audio_conditioning} needs a download; this build runs offline")
+            return _import_model_state(audio_conditioning, self.device)
+        if isinstance(audio_conditioning, str) and audio_conditioning in PREDEFINED_VOICES:
+            if self.origin is None or not self.origin.is_relative_to(CONFIGS_DIR):
+                raise ValueError("Cannot use predefined voices when the model is not loaded from a config "
+                                 f"associated with a language.Here the origin is {self.origin}")
+            raise FileNotFoundError(f"predefined voice '{audio_conditioning}' needs a download; this build runs "
+                                    "offline: pass a local .safetensors voice state instead")
+        raise ValueError(
+            "We could not load the model with voice cloning: encoding an audio prompt needs the Mimi encoder, "
+            "which is not part of the MI355X hot-path build yet. Use a .safetensors voice state exported by the "
+            "reference (export_model_state) or get_state_for_conditioning()."
+        )
+
+    def get_state_for_conditioning(self, conditioning: torch.Tensor) -> dict:
+        """Voice state from pre-computed speaker conditioning f32[1, T, d_model] (the output of the
+        reference's `_encode_audio`, tts_model.py:379-388).  Prepends `bos_before_voice` like
+        tts_model.py:893-894 and prefills the FlowLM."""
+        eng = self.engine
+        prompt = conditioning.to(self.device, torch.float32)
+        if self.config.flow_lm.insert_bos_before_voice:
+            prompt = torch.cat([eng.bos_before_voice, prompt], dim=1)
+        T = prompt.shape[1]
+        st = eng.new_lm_state(1, T)
+        eng.lm_prefill(st, prompt)
+        state = _export_lm_state(eng, st, T)
+        st.close()
+        return state
+
+    # ---- generation ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate_audio(self, model_state: dict, text_to_generate: str, max_tokens: int = MAX_TOKEN_PER_CHUNK,
+                       frames_after_eos: int | None = None, copy_state: bool = True) -> torch.Tensor:
+        chunks = list(self.generate_audio_stream(model_state, text_to_generate, max_tokens, frames_after_eos, copy_state))
+        return torch.cat(chunks, dim=0)
+
+    @torch.no_grad()
+    def generate_audio_stream(self, model_state: dict, text_to_generate: str, max_tokens: int = MAX_TOKEN_PER_CHUNK,
+                              frames_after_eos: int | None = None, copy_state: bool = True):
+        """Yields fp32 CPU tensors of `frame_samples` (1920) samples (reference tts_model.py:545-631)."""
+        if frames_after_eos is None:
+            frames_after_eos = self.model_recommended_frames_after_eos
+        chunks = split_into_best_sentences(self.tokenizer.encode, self.tokenizer.sp, text_to_generate, max_tokens,
+                                           self.pad_with_spaces_for_short_inputs, self.remove_semicolons)
+        for chunk in chunks:
+            _, guess = prepare_text_prompt(chunk, self.pad_with_spaces_for_short_inputs, self.remove_semicolons)
+            guess += 2
+            effective = frames_after_eos if frames_after_eos is not None else guess
+            yield from self._generate_audio_stream_short_text(model_state, chunk, effective, copy_state)
+
+    def _draw_noise(self, out: torch.Tensor):
+        """Same draws as the reference CPU path (flow_lm.py:131-137): torch's global CPU generator."""
+        std = self.temp ** 0.5
+        if self.noise_clamp is None:
+            torch.nn.init.normal_(out, mean=0.0, std=std)
+        else:
+            torch.nn.init.trunc_normal_(out, mean=0.0, std=std, a=-self.noise_clamp, b=self.noise_clamp)
+
+    def _generate_audio_stream_short_text(self, model_state: dict, text: str, frames_after_eos: int, copy_state: bool):
+        eng = self.engine
+        tokens = torch.tensor(self.tokenizer.encode(text), dtype=torch.long)[None, :]
+        Tt = tokens.shape[1]
+        max_gen_len = estimate_max_gen_len(Tt, self.config.mimi.frame_rate)
+        t_voice = _state_current_end(model_state)
+        st = eng.new_lm_state(1, t_voice + Tt + max_gen_len)
+        ms = eng.new_mimi_state(1)
+        t_start = time.monotonic()
+        _import_lm_state(eng, st, model_state, t_voice)       # replaces deepcopy + _expand_kv_cache
+        eng.lm_prefill(st, eng.embed_text(tokens))            # text prefill (tts_model.py:722-725)
+        dev = self.device
+        use_noise = self.temp > 0
+        noise_host = torch.zeros(1, eng.ldim).pin_memory()
+        if use_noise:
+            # the reference's text prefill runs the whole forward, including one (discarded) noise draw
+            # (tts_model.py:722-725 -> flow_lm.py:131-137): consume it to stay on the same generator stream
+            self._draw_noise(torch.empty(1, eng.ldim))
+        noise_dev = torch.zeros(1, eng.ldim, device=dev) if use_noise else None
+        lat = torch.empty(1, eng.ldim, device=dev)
+        logit = torch.empty(1, device=dev)
+        flag = torch.empty(1, dtype=torch.uint8, device=dev)
+        pcm = torch.empty(1, eng.frame_samples, device=dev)
+        flag_host = torch.zeros(1, dtype=torch.uint8).pin_memory()
+        eng.sync()
+        torch.cuda.synchronize(dev)
+        g_lm = eng.capture_lm_step(st, noise_dev, self.lsd_decode_steps, float(self.eos_threshold), lat, logit, flag)
+        g_mimi = eng.capture_mimi(ms, lat, pcm)
+        stream = eng.stream
+        total = 0
+        try:
+            eos_step = None
+            pending = None  # (host chunk, event) of the frame whose PCM copy is in flight
+            for step in range(max_gen_len):
+                if use_noise:
+                    self._draw_noise(noise_host)
+                    with torch.cuda.stream(stream):
+                        noise_dev.copy_(noise_host, non_blocking=True)
+                eng.graph_launch(g_lm)
+                with torch.cuda.stream(stream):
+                    flag_host.copy_(flag, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                # hand the previous frame to the consumer while the GPU runs this step
+                if pending is not None:
+                    pending[1].synchronize()
+                    total += pending[0].shape[0]
+                    yield pending[0]
+                    pending = None
+                ev.synchronize()  # the EOS decision is a host decision, as in the reference (:761)
+                if bool(flag_host.item()) and eos_step is None:
+                    eos_step = step
+                if eos_step is not None and step >= eos_step + frames_after_eos:
+                    break  # the break-step latent is not decoded (tts_model.py:763-764)
+                eng.graph_launch(g_mimi)
+                host = torch.empty(eng.frame_samples).pin_memory()
+                with torch.cuda.stream(stream):
+                    host.copy_(pcm[0], non_blocking=True)
+                pev = torch.cuda.Event()
+                pev.record(stream)
+                pending = (host, pev)
+            else:
+                logger.warning("Maximum generation length reached without EOS, this very often indicates an error.")
+            if pending is not None:
+                pending[1].synchronize()
+                total += pending[0].shape[0]
+                yield pending[0]
+            if not copy_state:
+                # the reference mutates the caller's state in place (tts_model.py:637-638)
+                n = int(st.offsets()[0])
+                model_state.update(_export_lm_state(eng, st, n))
+        finally:
+            eng.sync()
+            eng.graph_destroy(g_lm)
+            eng.graph_destroy(g_mimi)
+            st.close()
+            ms.close()
+        dur_ms = int(total * 1000 / self.config.mimi.sample_rate)
+        gen_ms = max(1, int((time.monotonic() - t_start) * 1000))
+        logger.info("Generated: %d ms of audio in %d ms so %.2fx faster than real-time", dur_ms, gen_ms, dur_ms / gen_ms)
+
+
+# ---- model-state helpers (reference format) ---------------------------------------------------
+def _layer_key(i: int) -> str:
+    return f"transformer.layers.{i}.self_attn"
+
+
+def _state_current_end(model_state: dict) -> int:
+    for ms in model_state.values():
+        off = ms.get("offset")
+        if off is not None:
+            return int(off.view(-1)[0].item())
+    raise ValueError("Could not find offset in model state")
+
+
+def _import_lm_state(eng: Engine, st, model_state: dict, t: int):
+    for i in range(eng.L):
+        st.import_layer(i, model_state[_layer_key(i)]["cache"], t)
+
+
+def _export_lm_state(eng: Engine, st, t: int) -> dict:
+    out = {}
+    for i in range(eng.L):
+        out[_layer_key(i)] = dict(cache=st.export_layer(i, t),
+                                  offset=torch.full((1,), t, dtype=torch.long, device=eng.device))
+    return out
+
+
+def export_model_state(model_state: dict, dest: str | Path):
+    """safetensors keys "<module>/<key>" (reference tts_model.py:1047-1052)."""
+    flat = {}
+    for module_name, module_state in model_state.items():
+        for key, value in module_state.items():
+            flat[f"{module_name}/{key}"] = value.detach().cpu().contiguous()
+    safetensors.torch.save_file(flat, str(dest))
+
+
+def _import_model_state(source: str | Path, device) -> dict:
+    """Reads a voice-state file, including the legacy `current_end` key whose shape[0] is the offset
+    (reference tts_model.py:1055-1072)."""
+    result: dict = {}
+    with safetensors.safe_open(str(source), framework="pt") as f:
+        for key in f.keys():
+            module_name, tensor_key = key.split("/")
+            result.setdefault(module_name, {})
+            if tensor_key == "current_end":
+                n = f.get_tensor(key).shape[0]
+                result[module_name]["offset"] = torch.full((1,), n, dtype=torch.long, device=device)
+            else:
+                result[module_name][tensor_key] = f.get_tensor(key).to(device)
+    return result

@@ -1,0 +1,109 @@
+"""End-to-end drop-in check on the GPU: `pocket_tts_amd.TTSModel` against waveforms produced by the
+reference's `TTSModel.generate_audio` on the same synthetic weights, voice-state file, tokenizer and
+text (fixtures: tests/golden/gen_golden_e2e.py).  Frame counts (= EOS decision sequence) must be EXACT;
+waveform max-abs error <= 5e-4."""
+
+import ast
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def fx():
+    z = np.load(G / "e2e_tiny.npz", allow_pickle=False)
+    d = {k: z[k] for k in z.files}
+    d["meta"] = ast.literal_eval(str(d["meta"]))
+    return d
+
+
+@pytest.fixture(scope="module")
+def model():
+    from pocket_tts_amd import TTSModel
+
+    m = TTSModel.load_model(config=G / "e2e_tiny.yaml", temp=0.0)
+    yield m
+    m.engine.close()
+
+
+def test_public_api():
+    import pocket_tts_amd
+
+    assert pocket_tts_amd.__all__ == ["TTSModel", "export_model_state"]
+    for name in ("load_model", "generate_audio", "generate_audio_stream", "get_state_for_audio_prompt"):
+        assert hasattr(pocket_tts_amd.TTSModel, name)
+
+
+def test_generate_audio_temp0(model, fx):
+    state = model.get_state_for_audio_prompt(G / "e2e_voice.safetensors")
+    wav = model.generate_audio(state, fx["meta"]["text"], frames_after_eos=2)
+    assert wav.dtype == torch.float32 and wav.dim() == 1
+    assert wav.shape[0] == fx["e2e_wav_temp0"].shape[0]
+    assert np.abs(wav.numpy() - fx["e2e_wav_temp0"]).max() < 5e-4
+    assert model.sample_rate == 24000 and model.device.type == "cuda"
+
+
+def test_generate_audio_stream_chunks_and_seeded_noise(model, fx):
+    """temp 0.7: noise is drawn from torch's global CPU generator exactly like the reference CPU path,
+    so a seeded run reproduces the reference waveform."""
+    state = model.get_state_for_audio_prompt(G / "e2e_voice.safetensors")
+    model.temp = 0.7
+    torch.manual_seed(fx["meta"]["seed_temp07"])
+    chunks = list(model.generate_audio_stream(state, fx["meta"]["text"]))
+    model.temp = 0.0
+    assert all(c.shape == (1920,) for c in chunks)
+    wav = torch.cat(chunks).numpy()
+    assert wav.shape == fx["e2e_wav_temp07"].shape
+    assert np.abs(wav - fx["e2e_wav_temp07"]).max() < 5e-4
+
+
+def test_max_length_without_eos(model, fx):
+    state = model.get_state_for_audio_prompt(G / "e2e_voice.safetensors")
+    thr = model.eos_threshold
+    model.eos_threshold = 1e9
+    try:
+        wav = model.generate_audio(state, "ok", frames_after_eos=1)
+    finally:
+        model.eos_threshold = thr
+    assert wav.shape[0] == fx["e2e_wav_noeos"].shape[0]
+    assert np.abs(wav.numpy() - fx["e2e_wav_noeos"]).max() < 1e-3
+
+
+def test_state_is_not_mutated_with_copy_state(model, fx):
+    state = model.get_state_for_audio_prompt(G / "e2e_voice.safetensors")
+    before = {k: v["cache"].clone() for k, v in state.items()}
+    model.generate_audio(state, "hello world", frames_after_eos=1)
+    for k, v in state.items():
+        assert torch.equal(v["cache"], before[k])
+
+
+def test_export_import_voice_state_roundtrip(model, tmp_path):
+    from pocket_tts_amd import export_model_state
+
+    cond = torch.randn(1, 7, model.engine.D) * 0.1
+    st = model.get_state_for_conditioning(cond)
+    assert int(st["transformer.layers.0.self_attn"]["offset"][0]) == 8  # bos_before_voice + 7
+    export_model_state(st, tmp_path / "v.safetensors")
+    st2 = model.get_state_for_audio_prompt(tmp_path / "v.safetensors")
+    for k in st:
+        assert torch.equal(st[k]["cache"].cpu(), st2[k]["cache"].cpu())
+        assert torch.equal(st[k]["offset"].cpu(), st2[k]["offset"].cpu())
+
+
+def test_errors_mirror_reference(model):
+    from pocket_tts_amd import TTSModel
+
+    with pytest.raises(ValueError):
+        TTSModel.load_model(language="english", config="x.yaml")
+    with pytest.raises(ValueError):
+        TTSModel.load_model(language="french")
+    with pytest.raises(FileNotFoundError):
+        TTSModel.load_model(config="/nonexistent/none.yaml")
+    state = model.get_state_for_audio_prompt(G / "e2e_voice.safetensors")
+    with pytest.raises(ValueError):
+        model.generate_audio(state, "   ")
