@@ -199,17 +199,12 @@ def cpu_baseline(args, cfg, W, nsteps):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
+    from pocket_tts_amd import parallel
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    rank, local, world = parallel.env_ranks()
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
+    dist = parallel.init_distributed("nccl", dev)  # RCCL; only barriers + scalar reductions
 
     from pocket_tts_amd.config import named_config
     from pocket_tts_amd.engine import Engine
@@ -237,14 +232,12 @@ def main():
     ev_ms = eng.timer_stop_ms()
     barrier()
     wall = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([wall], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    audio_total, wall = parallel.job_throughput(args.batch * args.steps * FRAME_S, wall, dist, dev)
+    audio_total *= wall  # job_throughput returns units/s; keep the totals explicit below
 
     out = None
     if rank == 0:
-        audio_s = world * args.batch * args.steps * FRAME_S
+        audio_s = audio_total
         out = {
             "metric": "audio-seconds/sec (xRT), 100M en model, whole job over all GPUs",
             "value": audio_s / wall,
