@@ -71,16 +71,10 @@ class Job:
         self.st = eng.new_lm_state(B, cap)
         self.ms = eng.new_mimi_state(B)
         self.st.set_noise(args.temp, 1234 + seed)
-        self.lat = torch.empty(B, eng.ldim, device=dev)
-        self.logit = torch.empty(B, device=dev)
-        self.flag = torch.empty(B, dtype=torch.uint8, device=dev)
-        self.pcm = torch.empty(B, eng.frame_samples, device=dev)
-        self.host_pcm = torch.empty(args.frames, B, eng.frame_samples).pin_memory()
-        eng.sync()
-        torch.cuda.synchronize()
         # EOS stop disabled (threshold +inf) so every utterance has exactly `frames` frames
-        self.g_lm = eng.capture_lm_step(self.st, None, 1, float("inf"), self.lat, self.logit, self.flag)
-        self.g_mimi = eng.capture_mimi(self.ms, eng.lm_latent(self.st), self.pcm)
+        from pocket_tts_amd.engine import StepPipeline
+
+        self.pipe = StepPipeline(eng, self.st, self.ms, None, 1, float("inf"), host_frames=args.frames)
         self.frame = args.frames  # forces a (re)start on the first step
 
     def start_utterances(self):
@@ -88,18 +82,17 @@ class Job:
         self.st.copy_from(self.voice)            # per-chunk state clone (tts_model.py:637-638)
         emb = eng.embed_text(self.tokens)        # LUT gather (text.py:74-76)
         eng.lm_prefill(self.st, emb)             # text prefill (tts_model.py:722-725)
-        self.ms.reset()
+        self.pipe.restart()
         self.frame = 0
 
     def step(self):
         if self.frame >= self.args.frames:
             self.start_utterances()
-        eng = self.eng
-        eng.graph_launch(self.g_lm)
-        eng.graph_launch(self.g_mimi)
-        with torch.cuda.stream(eng.stream):
-            self.host_pcm[self.frame].copy_(self.pcm, non_blocking=True)
+        self.pipe.step(host_slot=self.frame)
         self.frame += 1
+
+    def sync(self):
+        self.pipe.sync()
 
 
 def first_chunk_latency(eng, args, trials=60):
@@ -108,34 +101,27 @@ def first_chunk_latency(eng, args, trials=60):
     B = 1
     a = argparse.Namespace(**vars(args))
     job = Job(eng, B, a, seed=7)
-    lat_ms, step_us = [], []
-    host = torch.empty(B, eng.frame_samples).pin_memory()
+    lat_ms = []
     for t in range(trials + 5):
+        job.sync()
         eng.sync()
         t0 = time.perf_counter()
         job.start_utterances()
-        eng.graph_launch(job.g_lm)
-        eng.graph_launch(job.g_mimi)
-        with torch.cuda.stream(eng.stream):
-            host.copy_(job.pcm, non_blocking=True)
-        eng.sync()
+        job.pipe.step(host_slot=0)
+        job.sync()
         dt = (time.perf_counter() - t0) * 1e3
         if t >= 5:
             lat_ms.append(dt)
-    # steady-state per-step time of the B=1 graph pair (context ~ voice + text + 60)
-    for _ in range(60):
-        job.frame = 0
-        eng.graph_launch(job.g_lm)
-        eng.graph_launch(job.g_mimi)
-    eng.sync()
-    n = 50
+    # steady-state per-step time of the B=1 pipeline (one full utterance)
     job.start_utterances()
-    eng.sync()
+    for _ in range(20):
+        job.step()
+    job.sync()
+    n = 100
     t0 = time.perf_counter()
     for _ in range(n):
-        eng.graph_launch(job.g_lm)
-        eng.graph_launch(job.g_mimi)
-    eng.sync()
+        job.step()
+    job.sync()
     per_step_ms = (time.perf_counter() - t0) * 1e3 / n
     return dict(first_chunk_ms_p50=float(np.percentile(lat_ms, 50)), first_chunk_ms_p99=float(np.percentile(lat_ms, 99)),
                 b1_ms_per_step=per_step_ms, b1_xrt=FRAME_S * 1e3 / per_step_ms, trials=trials)
@@ -148,9 +134,11 @@ def kernel_profile(eng, job, nsteps=6):
         job.step()
     eng.sync()
     eng.profile_start()
+    job.sync()
+    P = job.pipe
     for _ in range(nsteps):
-        eng.lm_decode_step(job.st, None, None, 1, float("inf"), job.lat, job.logit, job.flag)
-        eng.mimi_decode(job.ms, job.lat, job.pcm)
+        eng.lm_decode_step(job.st, None, None, 1, float("inf"), P.lat, P.logit, P.flag)
+        eng.mimi_decode(job.ms, P.lat, P.pcm[0])
     rows = eng.profile_stop()
     job.frame = job.args.frames
     per_kernel = {}
@@ -216,6 +204,7 @@ def main():
     job = Job(eng, args.batch, args, seed=rank)
 
     def barrier():
+        job.sync()
         eng.sync()
         torch.cuda.synchronize()
         if dist is not None:
@@ -229,6 +218,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         job.step()
+    job.sync()
     ev_ms = eng.timer_stop_ms()
     barrier()
     wall = time.perf_counter() - t0
@@ -255,7 +245,7 @@ def main():
                 "workload": f"{args.config}: batch {args.batch} concurrent utterances/GPU, voice KV {args.voice_len} + "
                             f"text {args.text_len} tokens, {args.frames} frames (10 s) each, temp {args.temp}, "
                             f"lsd_decode_steps 1; per utterance: state clone + text prefill + FlowLM step + Mimi "
-                            f"decode per frame, hipGraph per step, PCM copied to pinned host memory",
+                            f"decode per frame, hipGraph per step on two streams (FlowLM step t+1 overlaps codec frame t), PCM copied to pinned host memory",
                 "batch_per_gpu": args.batch,
                 "parallelism": f"replicas x{world} (no collective on the data path)",
             },

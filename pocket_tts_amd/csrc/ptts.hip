@@ -96,7 +96,7 @@ struct ptts_engine {
 };
 
 struct Scratch {
-  float *x = nullptr, *h = nullptr, *ao = nullptr, *ff = nullptr, *q = nullptr, *part = nullptr;
+  float *x = nullptr, *h = nullptr, *ao = nullptr, *ff = nullptr, *q = nullptr, *part = nullptr, *rope = nullptr;
   int MT = 0, QB = 0, splits_cap = 0;
 };
 
@@ -127,12 +127,12 @@ struct ptts_mimi_state {
   int *frame = nullptr, *offset = nullptr;
   int h_frame = 0;
   float *kv = nullptr;  // [ML][2][B][H][ring][64]
-  float *zl, *zq, *u0, *u, *h, *ao, *ff, *q, *part, *tr_out;
+  float *zl, *zq, *u0, *u, *h, *ao, *ff, *q, *part, *tr_out, *rope;
   long zq_stride, tr_stride;
   int splits;
   float *a0;
   long a0_stride;
-  float *cbuf[3], *rbuf[3], *sbuf[3];
+  float *cbuf[3], *craw[3], *rbuf[3], *sbuf[3];  // cbuf/sbuf/rbuf hold ELU'd values, craw the raw skip input
   long c_stride[3], s_stride[3];
   int rows[4];  // rows per sequence at each SEANet stage
   float *pcm_dbg;
@@ -342,7 +342,10 @@ static void launch_ln(hipStream_t st, const float *X, long xds, int XF, float *Y
 }
 
 static int attn_splits(int base, int max_tiles) {
-  int s = std::max(1, 1024 / std::max(1, base));
+  // one wave per (sequence, head, query block, split): aim for >= 4096 waves (16 per CU) so that the KV
+  // stream has enough loads in flight; a split never gets less than ~2 key tiles
+  int s = std::max(1, cdiv(4096, std::max(1, base)));
+  s = std::min(s, std::max(1, max_tiles / 2));
   return std::max(1, std::min(s, max_tiles));
 }
 
@@ -357,7 +360,7 @@ struct TrCtx {
   float *h, *ao, *ff, *q, *part;
   float *Kc, *Vc;
   const int *offset;
-  const float *freq;
+  const float *rope;  // [M][32][2]
   double kv_keys;  // sum over sequences of the keys attended (profiling only)
   const char *tag;
 };
@@ -371,7 +374,7 @@ static void run_tr_layer(hipStream_t st, const TrLayer &T, const TrCtx &c) {
   SITE(s2.c_str());
   GemmArgs a = mk_gemm(T.qkv, c.h, DF, c.MT, c.M);
   a.epi = EPI_QKV;
-  a.Q = c.q; a.Kc = c.Kc; a.Vc = c.Vc; a.offset = c.offset; a.freq = c.freq;
+  a.Q = c.q; a.Kc = c.Kc; a.Vc = c.Vc; a.offset = c.offset; a.rope = c.rope;
   a.H = c.H; a.Tq = c.Tq; a.QB = c.QB; a.cap = c.cap; a.ring = c.ring;
   launch_gemm(st, a, PRE_NONE);
   AttnArgs at;
@@ -571,12 +574,13 @@ static int alloc_scratch(ptts_engine *e, Scratch *s, int B, int Tq, int D, int H
   CHK(dallocT(nullptr, &s->ao, rowt * (D / 16)));
   CHK(dallocT(nullptr, &s->ff, rowt * (FF / 16)));
   CHK(dallocT(nullptr, &s->q, (size_t)B * H * s->QB * 4 * 256));
+  CHK(dallocT(nullptr, &s->rope, (size_t)s->MT * 16 * 64));
   s->splits_cap = attn_splits(B * H * s->QB, cdiv(cap, 16));
   CHK(dallocT(nullptr, &s->part, (size_t)B * H * s->QB * s->splits_cap * 16 * ATT_PSTRIDE));
   return 0;
 }
 static void free_scratch(Scratch *s) {
-  hipFree(s->x); hipFree(s->h); hipFree(s->ao); hipFree(s->ff); hipFree(s->q); hipFree(s->part);
+  hipFree(s->x); hipFree(s->h); hipFree(s->ao); hipFree(s->ff); hipFree(s->q); hipFree(s->part); hipFree(s->rope);
   *s = Scratch();
 }
 
@@ -755,6 +759,11 @@ extern "C" int64_t ptts_profile_stop(ptts_engine *e, char *h_out, int64_t capaci
 
 static void lm_layers(hipStream_t st, ptts_engine *e, ptts_lm_state *s, Scratch &sc, int M, int Tq) {
   const ptts_config &c = e->cfg;
+  SITE("lm.rope");
+  {
+    ProfScope ps(st, "rope_table", 256.0 * M, 0);
+    rope_table_kernel<<<cdiv(M * 32, 256), 256, 0, st>>>(s->offset, e->freq_lm, sc.rope, M, Tq);
+  }
   for (int l = 0; l < c.num_layers; ++l) {
     TrCtx t;
     t.D = c.d_model; t.H = c.num_heads; t.FF = c.ff_dim; t.MT = sc.MT; t.M = M; t.Tq = Tq; t.QB = sc.QB;
@@ -762,7 +771,7 @@ static void lm_layers(hipStream_t st, ptts_engine *e, ptts_lm_state *s, Scratch 
     t.splits = std::min(sc.splits_cap, attn_splits(s->B * c.num_heads * sc.QB, cdiv(s->cap, 16)));
     t.x_in = sc.x; t.x = sc.x; t.x_out = sc.x; t.out_ds = 0; t.par = nullptr;
     t.h = sc.h; t.ao = sc.ao; t.ff = sc.ff; t.q = sc.q; t.part = sc.part;
-    t.Kc = s->K(l); t.Vc = s->V(l); t.offset = s->offset; t.freq = e->freq_lm;
+    t.Kc = s->K(l); t.Vc = s->V(l); t.offset = s->offset; t.rope = sc.rope;
     t.kv_keys = 0;
     for (int b = 0; b < s->B; ++b) t.kv_keys += s->h_off[b] + Tq;
     t.tag = "lm";
@@ -910,6 +919,7 @@ extern "C" int ptts_mimi_state_create(ptts_engine *e, int32_t B, ptts_mimi_state
   CHK(dallocT(nullptr, &s->ao, r16 * CF));
   CHK(dallocT(nullptr, &s->ff, r16 * (c.m_ff / 16)));
   CHK(dallocT(nullptr, &s->q, (size_t)B * c.m_heads * 4 * 256));
+  CHK(dallocT(nullptr, &s->rope, (size_t)B * 16 * 64));
   s->splits = attn_splits(B * c.m_heads, e->ring / 16);
   CHK(dallocT(nullptr, &s->part, (size_t)B * c.m_heads * s->splits * 16 * ATT_PSTRIDE));
   s->tr_stride = (long)r16 * CF;
@@ -926,6 +936,7 @@ extern "C" int ptts_mimi_state_create(ptts_engine *e, int32_t B, ptts_mimi_state
     s->c_stride[i] = (long)rt * (cout / 16);
     s->s_stride[i] = s->c_stride[i];
     CHK(dallocT(nullptr, &s->cbuf[i], (size_t)2 * s->c_stride[i]));
+    CHK(dallocT(nullptr, &s->craw[i], (size_t)s->c_stride[i]));
     CHK(dallocT(nullptr, &s->sbuf[i], (size_t)2 * s->s_stride[i]));
     CHK(dallocT(nullptr, &s->rbuf[i], rt * (hid / 16)));
     mult /= 2;
@@ -942,8 +953,8 @@ extern "C" void ptts_mimi_state_destroy(ptts_mimi_state *s) {
   hipDeviceSynchronize();
   hipFree(s->frame); hipFree(s->offset); hipFree(s->kv); hipFree(s->zl); hipFree(s->zq); hipFree(s->u0);
   hipFree(s->u); hipFree(s->h); hipFree(s->ao); hipFree(s->ff); hipFree(s->q); hipFree(s->part);
-  hipFree(s->tr_out); hipFree(s->a0); hipFree(s->pcm_dbg);
-  for (int i = 0; i < 3; ++i) { hipFree(s->cbuf[i]); hipFree(s->rbuf[i]); hipFree(s->sbuf[i]); }
+  hipFree(s->tr_out); hipFree(s->a0); hipFree(s->pcm_dbg); hipFree(s->rope);
+  for (int i = 0; i < 3; ++i) { hipFree(s->cbuf[i]); hipFree(s->craw[i]); hipFree(s->rbuf[i]); hipFree(s->sbuf[i]); }
   delete s;
 }
 
@@ -983,6 +994,11 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
     upsample_kernel<<<cdiv(tot, 256), 256, 0, st>>>(s->zq, s->zq_stride, s->frame, e->up_w, s->u0, B, C, st16);
   }
   const int M16 = B * st16;
+  SITE("mimi.rope");
+  {
+    ProfScope ps(st, "rope_table", 256.0 * M16, 0);
+    rope_table_kernel<<<cdiv(M16 * 32, 256), 256, 0, st>>>(s->offset, e->freq_mimi, s->rope, M16, st16);
+  }
   for (int l = 0; l < c.m_layers; ++l) {
     TrCtx t;
     t.D = C; t.H = c.m_heads; t.FF = c.m_ff; t.MT = s->MT16; t.M = M16; t.Tq = st16; t.QB = 1;
@@ -991,7 +1007,7 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
     const bool last = l == c.m_layers - 1;
     t.x_out = last ? s->tr_out : s->u; t.out_ds = last ? s->tr_stride : 0; t.par = last ? s->frame : nullptr;
     t.h = s->h; t.ao = s->ao; t.ff = s->ff; t.q = s->q; t.part = s->part;
-    t.Kc = s->K(l); t.Vc = s->V(l); t.offset = s->offset; t.freq = e->freq_mimi;
+    t.Kc = s->K(l); t.Vc = s->V(l); t.offset = s->offset; t.rope = s->rope;
     t.kv_keys = (double)B * std::min(e->ring, (s->h_frame + 1) * st16);
     t.tag = "mimi";
     run_tr_layer(st, e->mm[l], t);
@@ -1002,6 +1018,7 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
   a = mk_gemm(e->conv0, s->tr_out, CF, s->MT16, M16);
   a.Xdstride = s->tr_stride; a.T = s->rows[0]; a.par = s->frame;
   a.Y = s->a0; a.Ydstride = s->a0_stride; a.YF = mult * c.n_filters / 16;
+  a.act = ACT_ELU;  // every SEANet conv input is ELU(previous output): apply it once, in the producer
   launch_gemm(st, a, PRE_NONE);
   const float *xin = s->a0;
   long xds = s->a0_stride;
@@ -1016,19 +1033,20 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
     a = mk_gemm(e->convtr[i], xin, cin / 16, MTin, B * Tin);
     a.Xdstride = xds; a.T = Tin; a.par = s->frame;
     a.epi = EPI_CONVTR; a.cout = cout; a.stride = c.ratios[i];
-    a.Y = s->cbuf[i]; a.Ydstride = s->c_stride[i]; a.YF = cout / 16;
-    launch_gemm(st, a, PRE_ELU);
+    a.Y = s->cbuf[i]; a.Ydstride = s->c_stride[i]; a.YF = cout / 16; a.act = ACT_ELU;
+    a.Yraw = s->craw[i]; a.Yrawdstride = 0;  // raw value = the resnet block's skip input
+    launch_gemm(st, a, PRE_NONE);
     SITE(sn[i][1]);
     a = mk_gemm(e->res_a[i], s->cbuf[i], cout / 16, MTout, B * Tout);
     a.Xdstride = s->c_stride[i]; a.T = Tout; a.par = s->frame;
-    a.Y = s->rbuf[i]; a.YF = hid / 16;
-    launch_gemm(st, a, PRE_ELU);
+    a.Y = s->rbuf[i]; a.YF = hid / 16; a.act = ACT_ELU;
+    launch_gemm(st, a, PRE_NONE);
     SITE(sn[i][2]);
     a = mk_gemm(e->res_b[i], s->rbuf[i], hid / 16, MTout, B * Tout);
     a.T = Tout; a.par = s->frame;
-    a.epi = EPI_RES; a.R = s->cbuf[i]; a.Rdstride = s->c_stride[i]; a.RF = cout / 16;
+    a.epi = EPI_RES; a.R = s->craw[i]; a.Rdstride = 0; a.RF = cout / 16; a.act = ACT_ELU;
     a.Y = s->sbuf[i]; a.Ydstride = s->s_stride[i]; a.YF = cout / 16;
-    launch_gemm(st, a, PRE_ELU);
+    launch_gemm(st, a, PRE_NONE);
     xin = s->sbuf[i];
     xds = s->s_stride[i];
     mult /= 2;
@@ -1038,7 +1056,7 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
   a = mk_gemm(e->conv_last, xin, c.n_filters / 16, B * Tl / 16, B * Tl);
   a.Xdstride = xds; a.T = Tl; a.par = s->frame;
   a.epi = EPI_PCM; a.pcm = d_pcm ? d_pcm : s->pcm_dbg;
-  launch_gemm(st, a, PRE_ELU);
+  launch_gemm(st, a, PRE_NONE);
   SITE("mimi.tail");
   {
     ProfScope ps(st, "step_tail", 8.0 * B, 0);
@@ -1173,7 +1191,7 @@ extern "C" int64_t ptts_debug_read(ptts_engine *e, void *state, int32_t is_mimi,
       int mult = 8 >> stage;
       K = mult * c.n_filters / 2;
       M = B * s->rows[stage + 1];
-      src = is_res ? s->sbuf[stage] + par * s->s_stride[stage] : s->cbuf[stage] + par * s->c_stride[stage];
+      src = is_res ? s->sbuf[stage] + par * s->s_stride[stage] : s->craw[stage];
     }
     F = K / 16;
   }

@@ -30,11 +30,13 @@ enum { ACT_NONE = 0, ACT_GELU, ACT_SILU, ACT_ELU };
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float elu_f(float x) { return x > 0.0f ? x : expm1f(x); }
+// ELU in producer epilogues: exp(x) - 1 has an ABSOLUTE error of ~1e-7 near 0, far inside the 2e-4 parity bound
+__device__ __forceinline__ float elu_fast(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
 
 __device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
   if (act == ACT_GELU) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
   else if (act == ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-  else if (act == ACT_ELU) { v.x = elu_f(v.x); v.y = elu_f(v.y); v.z = elu_f(v.z); v.w = elu_f(v.w); }
+  else if (act == ACT_ELU) { v.x = elu_fast(v.x); v.y = elu_fast(v.y); v.z = elu_fast(v.z); v.w = elu_fast(v.w); }
   return v;
 }
 
@@ -58,6 +60,8 @@ struct GemmArgs {
   float *Y;
   long Ydstride;
   int YF;
+  float *Yraw;  // optional second output holding the value BEFORE `act` (same view shape as Y)
+  long Yrawdstride;
   const float *R;  // residual
   long Rdstride;
   int RF;
@@ -67,7 +71,7 @@ struct GemmArgs {
   // EPI_QKV
   float *Q, *Kc, *Vc;
   const int *offset;
-  const float *freq;  // [32] rotary frequencies
+  const float *rope;  // [M][32][2] (cos, sin) of pos * freq, built once per step by rope_table_kernel
   int H, Tq, QB, cap, ring;
   // EPI_HEAD
   float *eos_logit;
@@ -114,7 +118,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 acc, int 
       f32x4 rv = *(const f32x4 *)(r + (((size_t)mt * a.RF + nt) * 64 + lane) * 4);
       if (a.ls) acc *= *(const f32x4 *)(a.ls + n0);
       float *y = a.Y + par * a.Ydstride;
-      *(f32x4 *)(y + (((size_t)mt * a.YF + nt) * 64 + lane) * 4) = rv + acc;
+      *(f32x4 *)(y + (((size_t)mt * a.YF + nt) * 64 + lane) * 4) = act4(rv + acc, a.act);
     } break;
     case EPI_GATE: {
       f32x4 rv = *(const f32x4 *)(a.R + (((size_t)mt * a.RF + nt) * 64 + lane) * 4);
@@ -132,10 +136,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 acc, int 
       const int pos = a.offset[b] + t;
       if (which < 2) {
         // interleaved-pair RoPE in fp32 (reference rope.py:28-58)
-        float s0, c0, s1, c1;
-        const float fp = (float)pos;
-        sincosf(a.freq[d >> 1] * fp, &s0, &c0);
-        sincosf(a.freq[(d >> 1) + 1] * fp, &s1, &c1);
+        const f32x4 cs = *(const f32x4 *)(a.rope + ((size_t)m * 32 + (d >> 1)) * 2);  // cos0 sin0 cos1 sin1
+        const float c0 = cs.x, s0 = cs.y, c1 = cs.z, s1 = cs.w;
         f32x4 o;
         o.x = acc.x * c0 - acc.y * s0;
         o.y = acc.x * s0 + acc.y * c0;
@@ -178,8 +180,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 acc, int 
       const int j = n0 / a.cout;
       const int n = n0 - j * a.cout;
       const size_t mo = (size_t)m * a.stride + j;
+      const size_t idx = (((mo >> 4) * a.YF + (n >> 4)) * 64 + 16 * g + (mo & 15)) * 4;
+      if (a.Yraw) *(f32x4 *)(a.Yraw + par * a.Yrawdstride + idx) = acc;
       float *y = a.Y + par * a.Ydstride;
-      *(f32x4 *)(y + (((mo >> 4) * a.YF + (n >> 4)) * 64 + 16 * g + (mo & 15)) * 4) = acc;
+      *(f32x4 *)(y + idx) = act4(acc, a.act);
     } break;
     case EPI_PCM: {
       if (g == 0 && m < a.M) a.pcm[m] = acc.x;
@@ -203,11 +207,15 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
   const float *Xp = a.X + (par ^ 1) * a.Xdstride;
   const int k0 = (a.KF * wk) / WK, k1 = (a.KF * (wk + 1)) / WK;
 
-  f32x4 acc[TN][TM];
+  // a lone tile per wave would be one dependent MFMA chain: give it two accumulators (summed at the end)
+  constexpr int NACC = (TN * TM == 1) ? 2 : 1;
+  f32x4 acc[TN][TM][NACC];
 #pragma unroll
   for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int q = 0; q < NACC; ++q) acc[i][j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const float *wb[TN];
 #pragma unroll
@@ -263,46 +271,55 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
     for (int u = 0; u < UU; ++u) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) x[u][j] = pre4<PRE>(x[u][j], a.prevec, kf + u, lane);
+      // k-step major: back-to-back MFMAs hit DIFFERENT accumulators, so none waits out the 40-cycle
+      // dependent-accumulator latency of v_mfma_f32_16x16x4_f32 (issue interval 32 cycles)
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
+      for (int cidx = 0; cidx < 4; ++cidx)
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][i].x, x[u][j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][i].y, x[u][j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][i].z, x[u][j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][i].w, x[u][j].w, acc[i][j], 0, 0, 0);
-        }
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j][cidx % NACC] =
+                __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][i][cidx], x[u][j][cidx], acc[i][j][cidx % NACC], 0, 0, 0);
     }
   };
   int kf = k0;
   for (; kf + U <= k1; kf += U) step(std::integral_constant<int, U>{}, kf);
   for (; kf < k1; ++kf) step(std::integral_constant<int, 1>{}, kf);
 
+  f32x4 accs[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      accs[i][j] = acc[i][j][0];
+      if constexpr (NACC == 2) accs[i][j] += acc[i][j][1];
+    }
   if constexpr (WK > 1) {
-    __shared__ f32x4 red[(WK - 1) * WN * WM * TN * TM * 64];
+    // every wave parks its partial tiles in LDS; tile i*TM+j is then summed (fixed order) and finished by
+    // wave (i*TM+j) % WK, so the epilogues of a workgroup run on several SIMDs at once
+    __shared__ f32x4 red[WK * WN * WM * TN * TM * 64];
     const int grp = wave / WK;  // (wn, wm) group
-    if (wk > 0) {
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < TM; ++j)
-          red[((((wk - 1) * WN * WM + grp) * TN + i) * TM + j) * 64 + lane] = acc[i][j];
-    }
+      for (int j = 0; j < TM; ++j) red[(((wk * WN * WM + grp) * TN + i) * TM + j) * 64 + lane] = accs[i][j];
     __syncthreads();
-    if (wk == 0) {
-      for (int s = 0; s < WK - 1; ++s)
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-          for (int j = 0; j < TM; ++j) acc[i][j] += red[(((s * WN * WM + grp) * TN + i) * TM + j) * 64 + lane];
-    }
-  }
-  if (wk == 0) {
+      for (int j = 0; j < TM; ++j) {
+        if ((i * TM + j) % WK != wk) continue;
+        f32x4 sum = red[(((0 * WN * WM + grp) * TN + i) * TM + j) * 64 + lane];
+        for (int s2 = 1; s2 < WK; ++s2) sum += red[(((s2 * WN * WM + grp) * TN + i) * TM + j) * 64 + lane];
+        if (nt0 + i < a.NT && mt0 + j < a.MT) gemm_epilogue(a, sum, nt0 + i, mt0 + j, lane, par);
+      }
+  } else {
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
       for (int j = 0; j < TM; ++j)
-        if (nt0 + i < a.NT && mt0 + j < a.MT) gemm_epilogue(a, acc[i][j], nt0 + i, mt0 + j, lane, par);
+        if (nt0 + i < a.NT && mt0 + j < a.MT) gemm_epilogue(a, accs[i][j], nt0 + i, mt0 + j, lane, par);
   }
   (void)NW;
 }
@@ -468,6 +485,19 @@ __global__ void upsample_kernel(const float *zq, long zdstride, const int *par_p
   o.w = zc.w * w[(c + 3) * k2 + t] + zp.w * w[(c + 3) * k2 + s + t];
   long m = (long)b * s + t;
   *(f32x4 *)(out + (((size_t)(m >> 4) * CF + (c >> 4)) * 64 + 16 * ((c & 15) >> 2) + (m & 15)) * 4) = o;
+}
+
+// cos / sin of (offset[b] + t) * freq[i] for every row m = b*Tq + t, i < 32 (reference rope.py:28-50):
+// computed once per step instead of once per (layer, n-tile) in the QKV epilogue
+__global__ void rope_table_kernel(const int *offset, const float *freq, float *tab, int M, int Tq) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * 32) return;
+  int m = i >> 5, f = i & 31;
+  int b = m / Tq, t = m - b * Tq;
+  float sn, cs;
+  sincosf(freq[f] * (float)(offset[b] + t), &sn, &cs);
+  tab[2 * i] = cs;
+  tab[2 * i + 1] = sn;
 }
 
 __global__ void add_int_kernel(int *p, int n, int inc) {
@@ -667,22 +697,34 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
   const float *Vb = a.Vc + (size_t)bh * a.cap * 64;
   const int pq = q0 + c;
 
-  for (int tile = ts; tile < te; ++tile) {
+  f32x4 kn[4], vn[4];
+  auto load_tile = [&](int tile, f32x4 *kk, f32x4 *vv) {
     const int p0 = tile * 16;
     const int slot0 = a.ring ? (p0 % a.ring) : p0;
+#pragma unroll
+    for (int df = 0; df < 4; ++df) kk[df] = *(const f32x4 *)(Kb + (size_t)(slot0 + c) * 64 + 16 * df + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vv[r] = *(const f32x4 *)(Vb + (size_t)(slot0 + 4 * g + r) * 64 + 4 * c);
+  };
+  if (ts < te) load_tile(ts, kn, vn);
+  for (int tile = ts; tile < te; ++tile) {
+    const int p0 = tile * 16;
     f32x4 kf4[4], vf4[4];
 #pragma unroll
-    for (int df = 0; df < 4; ++df) kf4[df] = *(const f32x4 *)(Kb + (size_t)(slot0 + c) * 64 + 16 * df + 4 * g);
+    for (int i = 0; i < 4; ++i) { kf4[i] = kn[i]; vf4[i] = vn[i]; }
+    // the next tile's K/V are in flight while this tile's scores, softmax and P.V run
+    if (tile + 1 < te) load_tile(tile + 1, kn, vn);
+    // four independent accumulators (one per 16-wide slice of d), issued round-robin: no MFMA waits for
+    // the 40-cycle dependent-accumulator latency
+    f32x4 sp[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) vf4[r] = *(const f32x4 *)(Vb + (size_t)(slot0 + 4 * g + r) * 64 + 4 * c);
-    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int df = 0; df < 4; ++df) sp[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int df = 0; df < 4; ++df) {
-      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf4[df].x, qf[df].x, s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf4[df].y, qf[df].y, s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf4[df].z, qf[df].z, s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf4[df].w, qf[df].w, s, 0, 0, 0);
-    }
+    for (int cidx = 0; cidx < 4; ++cidx)
+#pragma unroll
+      for (int df = 0; df < 4; ++df)
+        sp[df] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf4[df][cidx], qf[df][cidx], sp[df], 0, 0, 0);
+    const f32x4 s = (sp[0] + sp[1]) + (sp[2] + sp[3]);
     // s[r] = score(key p0 + 4g + r, query c)
     bool ok[4];
     float mx = NEG_BIG;

@@ -111,8 +111,9 @@ class MimiState:
             self.engine.lib.ptts_mimi_state_destroy(self.handle)
             self.handle = None
 
-    def reset(self):
-        _lib.check(self.engine.lib.ptts_mimi_state_reset(self.handle, self.engine._sp))
+    def reset(self, stream: torch.cuda.Stream | None = None):
+        sp = self.engine._sp if stream is None else C.c_void_p(stream.cuda_stream)
+        _lib.check(self.engine.lib.ptts_mimi_state_reset(self.handle, sp))
 
     def __del__(self):
         try:
@@ -271,8 +272,9 @@ class Engine:
         _lib.check(self.lib.ptts_graph_capture_mimi(self.handle, state.handle, lp, _ptr(pcm), C.byref(g)))
         return g
 
-    def graph_launch(self, g):
-        _lib.check(self.lib.ptts_graph_launch(g, self._sp))
+    def graph_launch(self, g, stream: torch.cuda.Stream | None = None):
+        sp = self._sp if stream is None else C.c_void_p(stream.cuda_stream)
+        _lib.check(self.lib.ptts_graph_launch(g, sp))
 
     def graph_destroy(self, g):
         self.lib.ptts_graph_destroy(g)
@@ -316,3 +318,62 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+
+class StepPipeline:
+    """One hipGraph per FlowLM step and one per Mimi frame, on two streams: the FlowLM step of frame
+    t+1 runs while the codec decodes frame t (the reference pipelines the same two stages with two CPU
+    threads and a queue: tts_model.py:651-658,741-742).  Hand-off buffers are double-buffered by frame
+    parity and guarded by events, so no stage ever waits on the host."""
+
+    def __init__(self, eng: Engine, lm_state: LMState, mimi_state: MimiState, noise=None, lsd_steps: int = 1,
+                 eos_threshold: float = -4.0, host_frames: int = 0):
+        self.eng, self.st, self.ms = eng, lm_state, mimi_state
+        B, dev = lm_state.batch, eng.device
+        self.lat = torch.empty(B, eng.ldim, device=dev)
+        self.logit = torch.empty(B, device=dev)
+        self.flag = torch.empty(B, dtype=torch.uint8, device=dev)
+        self.zin = [torch.zeros(B, eng.ldim, device=dev) for _ in range(2)]
+        self.pcm = [torch.empty(B, eng.frame_samples, device=dev) for _ in range(2)]
+        self.host_pcm = torch.empty(max(1, host_frames), B, eng.frame_samples).pin_memory() if host_frames else None
+        self.s1 = eng.stream
+        self.s2 = torch.cuda.Stream(device=dev)
+        eng.sync()
+        torch.cuda.synchronize(dev)
+        self.g_lm = eng.capture_lm_step(lm_state, noise, lsd_steps, eos_threshold, self.lat, self.logit, self.flag)
+        self.g_mimi = [eng.capture_mimi(mimi_state, self.zin[p], self.pcm[p]) for p in range(2)]
+        self.e1 = [torch.cuda.Event() for _ in range(2)]
+        self.e2 = [torch.cuda.Event() for _ in range(2)]
+        for p in range(2):
+            self.e2[p].record(self.s2)
+        self.t = 0
+
+    def restart(self):
+        """new utterances: codec state back to zero carries (ordered after the frames still in flight)"""
+        self.ms.reset(self.s2)
+
+    def step(self, host_slot: int | None = None):
+        eng, p = self.eng, self.t & 1
+        eng.graph_launch(self.g_lm)                       # stream 1: FlowLM step t
+        self.s1.wait_event(self.e2[p])                    # zin[p] was last read by the codec at frame t-2
+        with torch.cuda.stream(self.s1):
+            self.zin[p].copy_(self.lat, non_blocking=True)
+        self.e1[p].record(self.s1)
+        self.s2.wait_event(self.e1[p])
+        eng.graph_launch(self.g_mimi[p], self.s2)         # stream 2: codec frame t
+        if host_slot is not None:
+            with torch.cuda.stream(self.s2):
+                self.host_pcm[host_slot].copy_(self.pcm[p], non_blocking=True)
+        self.e2[p].record(self.s2)
+        self.t += 1
+        return p
+
+    def sync(self):
+        self.s1.synchronize()
+        self.s2.synchronize()
+
+    def close(self):
+        self.sync()
+        self.eng.graph_destroy(self.g_lm)
+        for g in self.g_mimi:
+            self.eng.graph_destroy(g)

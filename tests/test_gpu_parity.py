@@ -96,6 +96,10 @@ def test_mimi_vs_golden(golden, case):
                 else:
                     got = eng.debug_read(ms, name).cpu().numpy()  # [B*T, C]
                     got = got.reshape(B, ref.shape[2], ref.shape[1]).transpose(0, 2, 1)
+                    if name in ("seanet0", "seanet3", "seanet6", "seanet9"):
+                        # these buffers hold ELU(output): the activation of the next layer is applied once,
+                        # by the producer (convtr raw outputs seanet2/5/8 are kept for the resnet skip)
+                        ref = np.where(ref > 0, ref, np.expm1(np.minimum(ref, 0)))
                 assert _maxerr(got, ref) < ATOL, f"{name} frame {f}"
         assert _maxerr(pcm.cpu().numpy(), g["pcm"][f]) < ATOL, f"pcm frame {f}"
 
@@ -216,3 +220,37 @@ def test_graph_replay_matches_eager():
         outs.append(res)
     for (a, pa), (b, pb) in zip(*outs):
         assert np.array_equal(a, b) and np.array_equal(pa, pb)
+
+
+def test_two_stream_pipeline_matches_eager():
+    """StepPipeline (FlowLM step t+1 overlapping codec frame t on a second stream, double-buffered
+    hand-off) must reproduce the sequential eager path bit for bit."""
+    from pocket_tts_amd.engine import StepPipeline
+
+    eng = get_engine("tiny")
+    B, Tp, ns = 3, 23, 9
+    rng = np.random.default_rng(11)
+    emb = dev((rng.standard_normal((B, Tp, eng.D)) * 0.5).astype(np.float32))
+    # eager
+    st, ms = eng.new_lm_state(B, Tp + ns), eng.new_mimi_state(B)
+    eng.lm_prefill(st, emb)
+    ref = []
+    for i in range(ns):
+        o, _, _ = eng.lm_decode_step(st, None, None, 1, -4.0)
+        pcm = eng.mimi_decode(ms, o)
+        torch.cuda.synchronize()
+        ref.append(pcm.cpu().numpy().copy())
+    # pipelined, twice (restart in between exercises the codec-state reset on the second stream)
+    st2, ms2 = eng.new_lm_state(B, Tp + ns), eng.new_mimi_state(B)
+    pipe = StepPipeline(eng, st2, ms2, None, 1, -4.0, host_frames=ns)
+    for rep in range(2):
+        st2.reset()
+        eng.lm_prefill(st2, emb)
+        pipe.restart()
+        for i in range(ns):
+            pipe.step(host_slot=i)
+        pipe.sync()
+        got = pipe.host_pcm.numpy()
+        for i in range(ns):
+            assert np.array_equal(got[i], ref[i]), (rep, i)
+    pipe.close()
