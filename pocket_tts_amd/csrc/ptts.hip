@@ -283,6 +283,9 @@ static void launch_cfg(hipStream_t st, const GemmArgs &a, int pre) {
 static int pick_cfg(const GemmArgs &a) {
   const long tiled = (long)cdiv(a.NT, 4) * cdiv(a.MT, 8);
   if (a.MT > 4 && tiled >= 192) return a.NT >= 4 ? 3 : a.NT >= 2 ? 4 : 5;
+  // few output tiles but a long K (Mimi FFN2 / conv k7 / out_proj at moderate batch): 2x4 tiles per wave,
+  // the 4 waves of a workgroup split K -> 4x the workgroups of the 2-D tiling at the same operand reuse
+  if (a.MT >= 8 && a.NT >= 2 && a.KF >= 32 && (long)cdiv(a.NT, 2) * cdiv(a.MT, 4) >= 128) return 7;
   if (a.MT > 64) {  // K-split would re-stream weights too often
     if (tiled < 192) return 6;  // small problem, many rows: one tile per wave for the largest grid
     return a.NT >= 4 ? 3 : a.NT >= 2 ? 4 : 5;
@@ -291,8 +294,8 @@ static int pick_cfg(const GemmArgs &a) {
   while (tm > 1 && (long)a.NT * cdiv(a.MT, tm) < 256) tm >>= 1;
   return tm == 4 ? 2 : tm == 2 ? 1 : 0;
 }
-static const char *const kCfgName[7] = {"gemm<1,1,8,1,1>", "gemm<1,2,8,1,1>", "gemm<1,4,8,1,1>", "gemm<2,4,1,2,2>",
-                                        "gemm<2,4,1,1,4>", "gemm<1,4,1,1,4>", "gemm<1,1,1,1,4>"};
+static const char *const kCfgName[8] = {"gemm<1,1,8,1,1>", "gemm<1,2,8,1,1>", "gemm<1,4,8,1,1>", "gemm<2,4,1,2,2>",
+                                        "gemm<2,4,1,1,4>", "gemm<1,4,1,1,4>", "gemm<1,1,1,1,4>", "gemm<2,4,4,1,1>"};
 
 static void launch_gemm(hipStream_t st, const GemmArgs &a, int pre) {
   // algorithmic traffic: weights once + input rows once (x taps re-read from cache, not counted) + output
@@ -308,7 +311,8 @@ static void launch_gemm(hipStream_t st, const GemmArgs &a, int pre) {
     case 3: launch_cfg<2, 4, 1, 2, 2>(st, a, pre); break;
     case 4: launch_cfg<2, 4, 1, 1, 4>(st, a, pre); break;
     case 5: launch_cfg<1, 4, 1, 1, 4>(st, a, pre); break;
-    default: launch_cfg<1, 1, 1, 1, 4>(st, a, pre); break;
+    case 6: launch_cfg<1, 1, 1, 1, 4>(st, a, pre); break;
+    default: launch_cfg<2, 4, 4, 1, 1>(st, a, pre); break;
   }
 }
 

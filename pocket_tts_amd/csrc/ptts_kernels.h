@@ -21,6 +21,12 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Ablation switches for tests/hip/bench_gemm.hip only (timing builds; results are wrong when set):
+// 1 = no X loads, 2 = no W loads, 4 = no MFMA.  Always 0 in the library.
+#ifndef PTTS_ABLATE
+#define PTTS_ABLATE 0
+#endif
+
 enum { PRE_NONE = 0, PRE_ELU = 1, PRE_ADDSILU = 2 };
 enum { EPI_STORE = 0, EPI_RES, EPI_GATE, EPI_QKV, EPI_HEAD, EPI_LATENT, EPI_CONVTR, EPI_PCM };
 enum { ACT_NONE = 0, ACT_GELU, ACT_SILU, ACT_ELU };
@@ -239,20 +245,24 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
     cf = k0 - tap * a.CF;
   }
   const int halo = a.ntaps - 1;
-  // U fragments per step: all 1 KiB loads of a step are issued before the first MFMA consumes one
-  constexpr int U = (TN * TM <= 2) ? 8 : 4;
-  auto step = [&](auto uc, int kf) {
+  // Software pipeline over chunks of U k-fragments: the 1 KiB operand loads of chunk c+1 are issued before the
+  // MFMAs of chunk c, into a second register set, so the matrix pipe works while the next operands fly.
+  constexpr int U = (TN * TM == 1) ? 8 : (TN * TM <= 4 && WK > 1) ? 4 : 2;
+  auto load_chunk = [&](auto uc, int kf, f32x4 (*w)[TN], f32x4 (*x)[TM]) {
     constexpr int UU = decltype(uc)::value;
-    f32x4 w[UU][TN], x[UU][TM];
 #pragma unroll
     for (int u = 0; u < UU; ++u) {
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         // weights are read exactly once by the K-split (decode) configuration: stream them non-temporally
-        if constexpr (WK > 1) w[u][i] = __builtin_nontemporal_load((const f32x4 *)(wb[i] + (size_t)(kf + u) * 256));
+        if constexpr (PTTS_ABLATE & 2) w[u][i] = (f32x4){1.f, 2.f, 3.f, (float)lane};
+        else if constexpr (WK > 1) w[u][i] = __builtin_nontemporal_load((const f32x4 *)(wb[i] + (size_t)(kf + u) * 256));
         else w[u][i] = *(const f32x4 *)(wb[i] + (size_t)(kf + u) * 256);
       }
-      if (a.ntaps == 1) {
+      if constexpr (PTTS_ABLATE & 1) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) x[u][j] = (f32x4){1.f, (float)lane, 3.f, (float)kf};
+      } else if (a.ntaps == 1) {
 #pragma unroll
         for (int j = 0; j < TM; ++j)
           x[u][j] = *(const f32x4 *)(Xc + (((size_t)mtc[j] * a.XF + kf + u) * 64 + lane) * 4);
@@ -267,6 +277,9 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
         if (++cf == a.CF) { cf = 0; ++tap; }
       }
     }
+  };
+  auto compute_chunk = [&](auto uc, int kf, f32x4 (*w)[TN], f32x4 (*x)[TM]) {
+    constexpr int UU = decltype(uc)::value;
 #pragma unroll
     for (int u = 0; u < UU; ++u) {
 #pragma unroll
@@ -278,14 +291,48 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
-          for (int j = 0; j < TM; ++j)
-            acc[i][j][cidx % NACC] =
-                __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][i][cidx], x[u][j][cidx], acc[i][j][cidx % NACC], 0, 0, 0);
+          for (int j = 0; j < TM; ++j) {
+            if constexpr (PTTS_ABLATE & 4) acc[i][j][cidx % NACC][cidx] += w[u][i][cidx] + x[u][j][cidx];
+            else
+              acc[i][j][cidx % NACC] =
+                  __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][i][cidx], x[u][j][cidx], acc[i][j][cidx % NACC], 0, 0, 0);
+          }
     }
   };
+  const std::integral_constant<int, U> cU{};
+  const std::integral_constant<int, 1> c1{};
   int kf = k0;
-  for (; kf + U <= k1; kf += U) step(std::integral_constant<int, U>{}, kf);
-  for (; kf < k1; ++kf) step(std::integral_constant<int, 1>{}, kf);
+  const int nfull = (k1 - k0) / U;
+  if constexpr (WK > 1 && TN * TM <= 4 && TN == 1) {
+    // decode (K-split) configurations: a wave owns only a few chunks, so every load is issued up front
+    // with one register set (high occupancy = more bytes in flight per CU) instead of double-buffering
+    for (int c = 0; c < nfull; ++c) {
+      f32x4 wA[U][TN], xA[U][TM];
+      load_chunk(cU, kf, wA, xA);
+      compute_chunk(cU, kf, wA, xA);
+      kf += U;
+    }
+  } else if (nfull > 0) {
+    f32x4 wA[U][TN], xA[U][TM], wB[U][TN], xB[U][TM];
+    load_chunk(cU, kf, wA, xA);
+    int c = 0;
+    for (; c + 2 <= nfull; c += 2) {
+      load_chunk(cU, kf + U, wB, xB);
+      compute_chunk(cU, kf, wA, xA);
+      if (c + 2 < nfull) load_chunk(cU, kf + 2 * U, wA, xA);
+      compute_chunk(cU, kf + U, wB, xB);
+      kf += 2 * U;
+    }
+    if (c < nfull) {
+      compute_chunk(cU, kf, wA, xA);
+      kf += U;
+    }
+  }
+  for (; kf < k1; ++kf) {
+    f32x4 w1[1][TN], x1[1][TM];
+    load_chunk(c1, kf, w1, x1);
+    compute_chunk(c1, kf, w1, x1);
+  }
 
   f32x4 accs[TN][TM];
 #pragma unroll
