@@ -74,7 +74,7 @@ class Job:
         # EOS stop disabled (threshold +inf) so every utterance has exactly `frames` frames
         from pocket_tts_amd.engine import StepPipeline
 
-        self.pipe = StepPipeline(eng, self.st, self.ms, None, 1, float("inf"), host_frames=args.frames)
+        self.pipe = StepPipeline(eng, self.st, self.ms, None, 1, float("inf"))
         self.frame = args.frames  # forces a (re)start on the first step
 
     def start_utterances(self):
@@ -88,8 +88,10 @@ class Job:
     def step(self):
         if self.frame >= self.args.frames:
             self.start_utterances()
-        self.pipe.step(host_slot=self.frame)
+        self.pipe.step()
         self.frame += 1
+        if self.frame >= self.args.frames:
+            self.pipe.flush()  # the utterances' last frame has no FlowLM step to ride along with
 
     def sync(self):
         self.pipe.sync()
@@ -107,7 +109,8 @@ def first_chunk_latency(eng, args, trials=60):
         eng.sync()
         t0 = time.perf_counter()
         job.start_utterances()
-        job.pipe.step(host_slot=0)
+        job.pipe.step()
+        job.pipe.flush()
         job.sync()
         dt = (time.perf_counter() - t0) * 1e3
         if t >= 5:
@@ -134,11 +137,13 @@ def kernel_profile(eng, job, nsteps=6):
         job.step()
     eng.sync()
     eng.profile_start()
+    job.pipe.flush()
     job.sync()
     P = job.pipe
+    pcm_dev = torch.empty(job.B, eng.frame_samples, device=eng.device)
     for _ in range(nsteps):
-        eng.lm_decode_step(job.st, None, None, 1, float("inf"), P.lat, P.logit, P.flag)
-        eng.mimi_decode(job.ms, P.lat, P.pcm[0])
+        eng.lm_decode_step(job.st, None, None, 1, float("inf"), P.lat[0], P.logit[0], None)
+        eng.mimi_decode(job.ms, P.lat[0], pcm_dev)
     rows = eng.profile_stop()
     job.frame = job.args.frames
     per_kernel = {}
@@ -245,7 +250,7 @@ def main():
                 "workload": f"{args.config}: batch {args.batch} concurrent utterances/GPU, voice KV {args.voice_len} + "
                             f"text {args.text_len} tokens, {args.frames} frames (10 s) each, temp {args.temp}, "
                             f"lsd_decode_steps 1; per utterance: state clone + text prefill + FlowLM step + Mimi "
-                            f"decode per frame, hipGraph per step on two streams (FlowLM step t+1 overlaps codec frame t), PCM copied to pinned host memory",
+                            f"decode per frame, one hipGraph per step with two parallel branches (FlowLM step t+1 || codec frame t), PCM written straight into pinned host memory",
                 "batch_per_gpu": args.batch,
                 "parallelism": f"replicas x{world} (no collective on the data path)",
             },

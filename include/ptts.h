@@ -107,12 +107,21 @@ int ptts_graph_capture_lm_step(ptts_engine *e, ptts_lm_state *s, const float *d_
                                uint8_t *d_is_eos, ptts_graph **out);
 int ptts_graph_capture_mimi(ptts_engine *e, ptts_mimi_state *s, const float *d_latent, float *d_pcm,
                             ptts_graph **out);
+/* One graph with two parallel branches: the FlowLM step (as ptts_graph_capture_lm_step) and the Mimi decode of
+ * the PREVIOUS frame (reads d_mimi_latent_in, which must differ from d_latent_out).  Replaying such graphs
+ * back to back on one stream overlaps step t+1 with frame t without cross-stream events (the reference
+ * pipelines the same two stages with two threads: tts_model.py:651-658). */
+int ptts_graph_capture_pipelined(ptts_engine *e, ptts_lm_state *s, ptts_mimi_state *m, const float *d_noise,
+                                 int32_t lsd_steps, float eos_threshold, float *d_latent_out, float *d_eos_logit,
+                                 uint8_t *d_is_eos, const float *d_mimi_latent_in, float *d_pcm, ptts_graph **out);
 int ptts_graph_launch(ptts_graph *g, void *stream);
 void ptts_graph_destroy(ptts_graph *g);
 
 /* ---- utilities */
 int ptts_sync(ptts_engine *e, void *stream);
 void *ptts_engine_stream(ptts_engine *e);
+/* asynchronous device -> pinned-host copy on `stream` (PCM chunks, EOS flags) */
+int ptts_copy_to_host_async(ptts_engine *e, void *h_dst, const void *d_src, int64_t bytes, void *stream);
 /* HIP-event timing on `stream` (bench.py measures on the stream the kernels run on) */
 int ptts_timer_start(ptts_engine *e, void *stream);
 int ptts_timer_stop_ms(ptts_engine *e, void *stream, float *h_ms);

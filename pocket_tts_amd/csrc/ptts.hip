@@ -878,9 +878,9 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
   }
   SITE("");
   hipMemcpyAsync(s->lat_prev, s->lat, (size_t)B * c.ldim * sizeof(float), hipMemcpyDeviceToDevice, st);
-  if (d_latent_out) hipMemcpyAsync(d_latent_out, s->lat, (size_t)B * c.ldim * sizeof(float), hipMemcpyDeviceToDevice, st);
-  if (d_eos_logit) hipMemcpyAsync(d_eos_logit, s->eos_logit, B * sizeof(float), hipMemcpyDeviceToDevice, st);
-  if (d_is_eos) hipMemcpyAsync(d_is_eos, s->is_eos, B, hipMemcpyDeviceToDevice, st);
+  if (d_latent_out) hipMemcpyAsync(d_latent_out, s->lat, (size_t)B * c.ldim * sizeof(float), hipMemcpyDefault, st);
+  if (d_eos_logit) hipMemcpyAsync(d_eos_logit, s->eos_logit, B * sizeof(float), hipMemcpyDefault, st);
+  if (d_is_eos) hipMemcpyAsync(d_is_eos, s->is_eos, B, hipMemcpyDefault, st);  // outputs may be pinned host memory
   return 0;
 }
 
@@ -1118,6 +1118,42 @@ extern "C" int ptts_graph_capture_mimi(ptts_engine *e, ptts_mimi_state *s, const
   return 0;
 }
 
+// One graph, two parallel branches: FlowLM step (writes d_latent_out) || Mimi decode of the PREVIOUS frame
+// (reads d_mimi_latent_in, a different buffer).  Fork/join inside the capture, so a replay needs no
+// cross-stream events: consecutive launches on one stream give step t+1 || frame t.
+extern "C" int ptts_graph_capture_pipelined(ptts_engine *e, ptts_lm_state *s, ptts_mimi_state *m, const float *d_noise,
+                                            int32_t lsd_steps, float eos_threshold, float *d_latent_out,
+                                            float *d_eos_logit, uint8_t *d_is_eos, const float *d_mimi_latent_in,
+                                            float *d_pcm, ptts_graph **out) {
+  HIPCHK(hipSetDevice(e->device));
+  CHK(prepare_lsd(e, lsd_steps));
+  ptts_graph *g = new ptts_graph();
+  g->lm = s;
+  g->mimi = m;
+  hipStream_t side;
+  hipEvent_t fork, join;
+  HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+  int rc = capture(e, g, [&](hipStream_t st) {
+    if (hipEventRecord(fork, st) != hipSuccess) return fail(-2, "fork record");
+    if (hipStreamWaitEvent(side, fork, 0) != hipSuccess) return fail(-2, "fork wait");
+    int r = lm_step_enqueue(st, e, s, nullptr, d_noise, lsd_steps, eos_threshold, d_latent_out, d_eos_logit, d_is_eos);
+    if (r < 0) return r;
+    r = mimi_enqueue(side, e, m, d_mimi_latent_in, d_pcm);
+    if (r < 0) return r;
+    if (hipEventRecord(join, side) != hipSuccess) return fail(-2, "join record");
+    if (hipStreamWaitEvent(st, join, 0) != hipSuccess) return fail(-2, "join wait");
+    return 0;
+  });
+  hipEventDestroy(fork);
+  hipEventDestroy(join);
+  hipStreamDestroy(side);
+  CHK(rc);
+  *out = g;
+  return 0;
+}
+
 extern "C" int ptts_graph_launch(ptts_graph *g, void *stream) {
   ptts_engine *e = g->lm ? g->lm->e : g->mimi->e;
   if (g->lm) {
@@ -1144,6 +1180,10 @@ extern "C" int ptts_sync(ptts_engine *e, void *stream) {
   return 0;
 }
 extern "C" void *ptts_engine_stream(ptts_engine *e) { return (void *)e->stream; }
+extern "C" int ptts_copy_to_host_async(ptts_engine *e, void *h_dst, const void *d_src, int64_t bytes, void *stream) {
+  HIPCHK(hipMemcpyAsync(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, S(e, stream)));
+  return 0;
+}
 extern "C" int ptts_timer_start(ptts_engine *e, void *stream) {
   HIPCHK(hipEventRecord(e->ev0, S(e, stream)));
   return 0;

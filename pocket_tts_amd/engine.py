@@ -276,6 +276,14 @@ class Engine:
         sp = self._sp if stream is None else C.c_void_p(stream.cuda_stream)
         _lib.check(self.lib.ptts_graph_launch(g, sp))
 
+    def copy_to_host_async(self, host: torch.Tensor, dev: torch.Tensor, stream: torch.cuda.Stream | None = None):
+        """device -> pinned host, truly asynchronous (torch's non_blocking copy_ blocks the host when the
+        destination is a view of a pinned tensor on this stack)"""
+        assert host.is_contiguous() and dev.is_contiguous() and host.numel() == dev.numel()
+        sp = self._sp if stream is None else C.c_void_p(stream.cuda_stream)
+        _lib.check(self.lib.ptts_copy_to_host_async(self.handle, C.c_void_p(host.data_ptr()), _ptr(dev),
+                                                    host.numel() * host.element_size(), sp))
+
     def graph_destroy(self, g):
         self.lib.ptts_graph_destroy(g)
 
@@ -321,59 +329,115 @@ class Engine:
 
 
 class StepPipeline:
-    """One hipGraph per FlowLM step and one per Mimi frame, on two streams: the FlowLM step of frame
-    t+1 runs while the codec decodes frame t (the reference pipelines the same two stages with two CPU
-    threads and a queue: tts_model.py:651-658,741-742).  Hand-off buffers are double-buffered by frame
-    parity and guarded by events, so no stage ever waits on the host."""
+    """hipGraph-per-step driver in which the FlowLM step of frame t+1 overlaps the codec decode of frame t
+    (the reference pipelines the same two stages with two CPU threads and a queue:
+    tts_model.py:651-658,741-742).  Latents ping-pong between two buffers; `pcm` buffers are pinned host
+    memory, so the codec's last kernel writes the samples straight over PCIe.  Two modes:
+
+    * "fork" (throughput, default for batch > 8): one graph per step with two parallel branches
+      {FlowLM step t -> lat[t&1]} || {Mimi decode of lat[(t-1)&1]}, launched back to back on one stream; the
+      host never waits.
+    * "hostsync" (latency, small batch): the host waits for FlowLM step t-1 (it needs its EOS flag anyway,
+      like the reference's `.item()` at tts_model.py:761), then launches the codec graph of frame t-1 on a
+      second stream while step t is already running on the first.  No cross-stream event wait sits on the
+      critical path (on this stack such waits around graph launches cost ~80 us per step, and the branches
+      of a forked graph do not run concurrently).
+    """
 
     def __init__(self, eng: Engine, lm_state: LMState, mimi_state: MimiState, noise=None, lsd_steps: int = 1,
-                 eos_threshold: float = -4.0, host_frames: int = 0):
+                 eos_threshold: float = -4.0, mode: str | None = None):
         self.eng, self.st, self.ms = eng, lm_state, mimi_state
         B, dev = lm_state.batch, eng.device
-        self.lat = torch.empty(B, eng.ldim, device=dev)
-        self.logit = torch.empty(B, device=dev)
-        self.flag = torch.empty(B, dtype=torch.uint8, device=dev)
-        self.zin = [torch.zeros(B, eng.ldim, device=dev) for _ in range(2)]
-        self.pcm = [torch.empty(B, eng.frame_samples, device=dev) for _ in range(2)]
-        self.host_pcm = torch.empty(max(1, host_frames), B, eng.frame_samples).pin_memory() if host_frames else None
-        self.s1 = eng.stream
+        self.mode = mode or ("hostsync" if B <= 8 else "fork")
+        self.lat = [torch.zeros(B, eng.ldim, device=dev) for _ in range(2)]
+        self.logit = [torch.empty(B, device=dev) for _ in range(2)]
+        self.flag = [torch.zeros(B, dtype=torch.uint8).pin_memory() for _ in range(2)]  # EOS flags land on the host
+        self.pcm = [torch.zeros(B, eng.frame_samples).pin_memory() for _ in range(2)]
+        self.ev = [torch.cuda.Event() for _ in range(2)]    # codec frame (f & 1) complete -> pcm_of(f) valid
+        self.ev_lm = [torch.cuda.Event() for _ in range(2)]  # FlowLM step (t & 1) complete -> flag valid
         self.s2 = torch.cuda.Stream(device=dev)
         eng.sync()
         torch.cuda.synchronize(dev)
-        self.g_lm = eng.capture_lm_step(lm_state, noise, lsd_steps, eos_threshold, self.lat, self.logit, self.flag)
-        self.g_mimi = [eng.capture_mimi(mimi_state, self.zin[p], self.pcm[p]) for p in range(2)]
-        self.e1 = [torch.cuda.Event() for _ in range(2)]
-        self.e2 = [torch.cuda.Event() for _ in range(2)]
+        lib, H = eng.lib, eng.handle
+        self.g_first = [eng.capture_lm_step(lm_state, noise, lsd_steps, eos_threshold, self.lat[p], self.logit[p],
+                                            self.flag[p]) for p in range(2)]
+        self.g_last = [eng.capture_mimi(mimi_state, self.lat[p], self.pcm[p]) for p in range(2)]
+        self.g_both = []
+        if self.mode == "fork":
+            for p in range(2):
+                g = C.c_void_p()
+                _lib.check(lib.ptts_graph_capture_pipelined(
+                    H, lm_state.handle, mimi_state.handle, _ptr(noise), lsd_steps, eos_threshold, _ptr(self.lat[p]),
+                    _ptr(self.logit[p]), _ptr(self.flag[p]), _ptr(self.lat[p ^ 1]), _ptr(self.pcm[p ^ 1]), C.byref(g)))
+                self.g_both.append(g)
         for p in range(2):
-            self.e2[p].record(self.s2)
-        self.t = 0
+            self.ev[p].record(self.s2)
+        self.t = 0          # FlowLM steps launched for the current utterances
+        self.decoded = 0    # codec frames launched
 
     def restart(self):
-        """new utterances: codec state back to zero carries (ordered after the frames still in flight)"""
-        self.ms.reset(self.s2)
+        """new utterances: flush the pending frame, codec state back to zero carries"""
+        self.flush()
+        if self.mode == "hostsync":
+            self.s2.synchronize()
+        self.ms.reset()
+        self.t = 0
+        self.decoded = 0
 
-    def step(self, host_slot: int | None = None):
+    def _decode_pending(self):
+        """hostsync mode: wait for FlowLM step t-1 on the host, then start its codec frame on stream 2"""
+        f = self.decoded
+        q = f & 1
+        self.ev_lm[q].synchronize()
+        self.eng.graph_launch(self.g_last[q], self.s2)
+        self.ev[q].record(self.s2)
+        self.decoded += 1
+        return f
+
+    def step(self):
+        """Launch FlowLM step t and the decode of frame t-1.  Returns the index of the frame whose PCM is
+        complete when `ev[frame & 1]` fires (None for the first step).  After the call,
+        `flag[(t-1) & 1]` (hostsync mode) holds the EOS flags of step t-1."""
         eng, p = self.eng, self.t & 1
-        eng.graph_launch(self.g_lm)                       # stream 1: FlowLM step t
-        self.s1.wait_event(self.e2[p])                    # zin[p] was last read by the codec at frame t-2
-        with torch.cuda.stream(self.s1):
-            self.zin[p].copy_(self.lat, non_blocking=True)
-        self.e1[p].record(self.s1)
-        self.s2.wait_event(self.e1[p])
-        eng.graph_launch(self.g_mimi[p], self.s2)         # stream 2: codec frame t
-        if host_slot is not None:
-            with torch.cuda.stream(self.s2):
-                self.host_pcm[host_slot].copy_(self.pcm[p], non_blocking=True)
-        self.e2[p].record(self.s2)
+        done = None
+        if self.mode == "fork":
+            if self.decoded < self.t:
+                eng.graph_launch(self.g_both[p])
+                self.ev[p ^ 1].record(eng.stream)
+                self.decoded += 1
+                done = self.decoded - 1
+            else:
+                eng.graph_launch(self.g_first[p])
+        else:
+            eng.stream.wait_event(self.ev[p])  # frame t-2 decoded: lat[p] / pcm[p] may be reused (long done)
+            eng.graph_launch(self.g_first[p])
+            self.ev_lm[p].record(eng.stream)
+            if self.decoded < self.t:
+                done = self._decode_pending()
         self.t += 1
-        return p
+        return done
+
+    def flush(self):
+        """decode the last pending frame (no FlowLM step rides along)"""
+        if self.decoded >= self.t:
+            return None
+        if self.mode == "hostsync":
+            return self._decode_pending()
+        p = (self.t - 1) & 1
+        self.eng.graph_launch(self.g_last[p])
+        self.ev[p].record(self.eng.stream)
+        self.decoded += 1
+        return self.decoded - 1
+
+    def pcm_of(self, frame: int) -> torch.Tensor:
+        """host tensor [B, frame_samples] of `frame` (valid after ev[frame & 1].synchronize())"""
+        return self.pcm[frame & 1]
 
     def sync(self):
-        self.s1.synchronize()
+        self.eng.stream.synchronize()
         self.s2.synchronize()
 
     def close(self):
         self.sync()
-        self.eng.graph_destroy(self.g_lm)
-        for g in self.g_mimi:
+        for g in self.g_first + self.g_last + self.g_both:
             self.eng.graph_destroy(g)

@@ -222,16 +222,16 @@ def test_graph_replay_matches_eager():
         assert np.array_equal(a, b) and np.array_equal(pa, pb)
 
 
-def test_two_stream_pipeline_matches_eager():
-    """StepPipeline (FlowLM step t+1 overlapping codec frame t on a second stream, double-buffered
-    hand-off) must reproduce the sequential eager path bit for bit."""
+def test_pipelined_graph_matches_eager():
+    """StepPipeline (one graph per step with two parallel branches: FlowLM step t+1 || codec frame t,
+    ping-pong latent buffers, PCM written into pinned host memory) must reproduce the sequential eager
+    path bit for bit."""
     from pocket_tts_amd.engine import StepPipeline
 
     eng = get_engine("tiny")
     B, Tp, ns = 3, 23, 9
     rng = np.random.default_rng(11)
     emb = dev((rng.standard_normal((B, Tp, eng.D)) * 0.5).astype(np.float32))
-    # eager
     st, ms = eng.new_lm_state(B, Tp + ns), eng.new_mimi_state(B)
     eng.lm_prefill(st, emb)
     ref = []
@@ -240,17 +240,26 @@ def test_two_stream_pipeline_matches_eager():
         pcm = eng.mimi_decode(ms, o)
         torch.cuda.synchronize()
         ref.append(pcm.cpu().numpy().copy())
-    # pipelined, twice (restart in between exercises the codec-state reset on the second stream)
+    for mode in ("fork", "hostsync"):
+        _run_pipeline_mode(eng, mode, B, Tp, ns, emb, ref)
+
+
+def _run_pipeline_mode(eng, mode, B, Tp, ns, emb, ref):
+    from pocket_tts_amd.engine import StepPipeline
+
     st2, ms2 = eng.new_lm_state(B, Tp + ns), eng.new_mimi_state(B)
-    pipe = StepPipeline(eng, st2, ms2, None, 1, -4.0, host_frames=ns)
-    for rep in range(2):
+    pipe = StepPipeline(eng, st2, ms2, None, 1, -4.0, mode=mode)
+    for rep in range(2):  # the second pass exercises restart()
         st2.reset()
         eng.lm_prefill(st2, emb)
         pipe.restart()
+        got = {}
+        for i in range(ns + 1):
+            f = pipe.step() if i < ns else pipe.flush()
+            if f is not None:
+                pipe.ev[f & 1].synchronize()
+                got[f] = pipe.pcm_of(f).numpy().copy()
+        assert sorted(got) == list(range(ns))
         for i in range(ns):
-            pipe.step(host_slot=i)
-        pipe.sync()
-        got = pipe.host_pcm.numpy()
-        for i in range(ns):
-            assert np.array_equal(got[i], ref[i]), (rep, i)
+            assert np.array_equal(got[i], ref[i]), (mode, rep, i)
     pipe.close()
