@@ -417,6 +417,28 @@ class StepPipeline:
         self.t += 1
         return done
 
+    # ---- building blocks for a host-driven loop with an EOS decision per step (TTSModel) ----------
+    def lm_step_async(self) -> int:
+        """launch FlowLM step t on stream 1; returns t"""
+        p = self.t & 1
+        self.eng.stream.wait_event(self.ev[p])  # frame t-2 decoded: lat[p] may be overwritten
+        self.eng.graph_launch(self.g_first[p])
+        self.ev_lm[p].record(self.eng.stream)
+        self.t += 1
+        return self.t - 1
+
+    def wait_flags(self, step: int) -> torch.Tensor:
+        """host waits for FlowLM step `step`; returns its EOS flags u8[B] (pinned host memory)"""
+        self.ev_lm[step & 1].synchronize()
+        return self.flag[step & 1]
+
+    def decode_async(self, frame: int):
+        """launch the codec decode of `frame` on stream 2 (call after wait_flags(frame))"""
+        q = frame & 1
+        self.eng.graph_launch(self.g_last[q], self.s2)
+        self.ev[q].record(self.s2)
+        self.decoded = frame + 1
+
     def flush(self):
         """decode the last pending frame (no FlowLM step rides along)"""
         if self.decoded >= self.t:

@@ -87,6 +87,7 @@ class TTSModel:
         self.eos_threshold = eos_threshold
         self.origin = origin
         self.has_voice_cloning = False  # the Mimi encoder path is not part of this build yet
+        self._ctx_cache: dict = {}
         self.pad_with_spaces_for_short_inputs = config.pad_with_spaces_for_short_inputs
         self.model_recommended_frames_after_eos = config.model_recommended_frames_after_eos
         self.remove_semicolons = config.remove_semicolons
@@ -201,77 +202,74 @@ class TTSModel:
         Tt = tokens.shape[1]
         max_gen_len = estimate_max_gen_len(Tt, self.config.mimi.frame_rate)
         t_voice = _state_current_end(model_state)
-        st = eng.new_lm_state(1, t_voice + Tt + max_gen_len)
-        ms = eng.new_mimi_state(1)
+        use_noise = self.temp > 0
         t_start = time.monotonic()
+        # states, scratch and captured graphs are reused across chunks and calls (capacity rounded up)
+        cap = -(-(t_voice + Tt + max_gen_len) // 256) * 256
+        key = (cap, self.lsd_decode_steps, float(self.eos_threshold), use_noise)
+        ctx = self._ctx_cache.pop(key, None)
+        if ctx is None:
+            from .engine import StepPipeline
+
+            st = eng.new_lm_state(1, cap)
+            ms = eng.new_mimi_state(1)
+            noise_dev = torch.zeros(1, eng.ldim, device=self.device) if use_noise else None
+            pipe = StepPipeline(eng, st, ms, noise_dev, self.lsd_decode_steps, float(self.eos_threshold), mode="hostsync")
+            ctx = dict(st=st, ms=ms, noise_dev=noise_dev, pipe=pipe)
+        st, ms, noise_dev, pipe = ctx["st"], ctx["ms"], ctx["noise_dev"], ctx["pipe"]
+        st.reset()
+        pipe.restart()
         _import_lm_state(eng, st, model_state, t_voice)       # replaces deepcopy + _expand_kv_cache
         eng.lm_prefill(st, eng.embed_text(tokens))            # text prefill (tts_model.py:722-725)
-        dev = self.device
-        use_noise = self.temp > 0
         noise_host = torch.zeros(1, eng.ldim).pin_memory()
         if use_noise:
             # the reference's text prefill runs the whole forward, including one (discarded) noise draw
             # (tts_model.py:722-725 -> flow_lm.py:131-137): consume it to stay on the same generator stream
             self._draw_noise(torch.empty(1, eng.ldim))
-        noise_dev = torch.zeros(1, eng.ldim, device=dev) if use_noise else None
-        lat = torch.empty(1, eng.ldim, device=dev)
-        logit = torch.empty(1, device=dev)
-        flag = torch.empty(1, dtype=torch.uint8, device=dev)
-        pcm = torch.empty(1, eng.frame_samples, device=dev)
-        flag_host = torch.zeros(1, dtype=torch.uint8).pin_memory()
-        eng.sync()
-        torch.cuda.synchronize(dev)
-        g_lm = eng.capture_lm_step(st, noise_dev, self.lsd_decode_steps, float(self.eos_threshold), lat, logit, flag)
-        g_mimi = eng.capture_mimi(ms, lat, pcm)
-        stream = eng.stream
         total = 0
         try:
             eos_step = None
-            pending = None  # (host chunk, event) of the frame whose PCM copy is in flight
+            emitted = 0    # frames handed to the codec
+            yielded = 0    # frames handed to the caller
+
+            def pop(frame):
+                pipe.ev[frame & 1].synchronize()
+                return pipe.pcm_of(frame)[0].clone()
+
             for step in range(max_gen_len):
                 if use_noise:
                     self._draw_noise(noise_host)
-                    with torch.cuda.stream(stream):
+                    with torch.cuda.stream(eng.stream):
                         noise_dev.copy_(noise_host, non_blocking=True)
-                eng.graph_launch(g_lm)
-                with torch.cuda.stream(stream):
-                    flag_host.copy_(flag, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(stream)
-                # hand the previous frame to the consumer while the GPU runs this step
-                if pending is not None:
-                    pending[1].synchronize()
-                    total += pending[0].shape[0]
-                    yield pending[0]
-                    pending = None
-                ev.synchronize()  # the EOS decision is a host decision, as in the reference (:761)
-                if bool(flag_host.item()) and eos_step is None:
+                pipe.lm_step_async()
+                # hand finished frames to the consumer while the GPU runs this step
+                while yielded < emitted:
+                    chunk = pop(yielded)
+                    yielded += 1
+                    total += chunk.shape[0]
+                    yield chunk
+                # the EOS decision is a host decision, as in the reference (tts_model.py:761)
+                if bool(pipe.wait_flags(step)[0].item()) and eos_step is None:
                     eos_step = step
                 if eos_step is not None and step >= eos_step + frames_after_eos:
                     break  # the break-step latent is not decoded (tts_model.py:763-764)
-                eng.graph_launch(g_mimi)
-                host = torch.empty(eng.frame_samples).pin_memory()
-                with torch.cuda.stream(stream):
-                    host.copy_(pcm[0], non_blocking=True)
-                pev = torch.cuda.Event()
-                pev.record(stream)
-                pending = (host, pev)
+                pipe.decode_async(step)  # codec frame `step` overlaps FlowLM step `step + 1`
+                emitted += 1
             else:
                 logger.warning("Maximum generation length reached without EOS, this very often indicates an error.")
-            if pending is not None:
-                pending[1].synchronize()
-                total += pending[0].shape[0]
-                yield pending[0]
+            while yielded < emitted:
+                chunk = pop(yielded)
+                yielded += 1
+                total += chunk.shape[0]
+                yield chunk
             if not copy_state:
                 # the reference mutates the caller's state in place (tts_model.py:637-638)
+                pipe.sync()
                 n = int(st.offsets()[0])
                 model_state.update(_export_lm_state(eng, st, n))
         finally:
-            eng.sync()
-            eng.graph_destroy(g_lm)
-            eng.graph_destroy(g_mimi)
-            st.close()
-            ms.close()
+            pipe.sync()
+            self._ctx_cache[key] = ctx
         dur_ms = int(total * 1000 / self.config.mimi.sample_rate)
         gen_ms = max(1, int((time.monotonic() - t_start) * 1000))
         logger.info("Generated: %d ms of audio in %d ms so %.2fx faster than real-time", dur_ms, gen_ms, dur_ms / gen_ms)
