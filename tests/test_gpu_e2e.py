@@ -107,3 +107,19 @@ def test_errors_mirror_reference(model):
     state = model.get_state_for_audio_prompt(G / "e2e_voice.safetensors")
     with pytest.raises(ValueError):
         model.generate_audio(state, "   ")
+
+
+def test_cli_generate_writes_wav(tmp_path):
+    """drop-in CLI surface: exit code 0, mono 24 kHz 16-bit WAV, non-empty (reference tests/test_cli_generate.py)"""
+    import wave
+
+    from pocket_tts_amd.main import cli_app
+
+    out = tmp_path / "o.wav"
+    rc = cli_app(["generate", "--config", str(G / "e2e_tiny.yaml"), "--voice", str(G / "e2e_voice.safetensors"),
+                  "--text", "Hello world. This is a test.", "--temperature", "0", "--output-path", str(out), "-q"])
+    assert rc == 0 and out.exists()
+    with wave.open(str(out), "rb") as w:
+        assert w.getnchannels() == 1 and w.getframerate() == 24000 and w.getsampwidth() == 2
+        n = w.getnframes()
+    assert n >= 1920 + 4800  # at least one frame + 200 ms of silence

@@ -1,0 +1,60 @@
+"""CPU checks of the host logic: config schema, weight inventory, WAV writer."""
+
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+from pocket_tts_amd.config import CONFIGS_DIR, config_from_dict, config_to_dict, load_config, named_config
+from pocket_tts_amd.weights import count_params, flow_lm_spec, generate_tensor, mimi_decode_spec, state_dict_spec
+
+
+def test_all_language_configs_load():
+    files = sorted(CONFIGS_DIR.glob("*.yaml"))
+    assert len(files) == 12
+    for f in files:
+        c = load_config(f)
+        assert c.flow_lm.transformer.num_layers in (6, 24)
+        assert c.frame_samples == 1920 and c.upsample_stride == 16
+    assert load_config(CONFIGS_DIR / "french_24l.yaml").model_recommended_frames_after_eos == 8
+
+
+def test_config_is_strict_and_missing_file_raises():
+    d = config_to_dict(named_config("tiny"))
+    d["flow_lm"]["bogus"] = 1
+    with pytest.raises(ValueError):
+        config_from_dict(d)
+    with pytest.raises(FileNotFoundError):
+        load_config(CONFIGS_DIR / "klingon.yaml")
+
+
+def test_param_counts_match_survey():
+    """FlowLM 89.41 M total; decode-side Mimi 10.31 M"""
+    cfg = named_config("en100m")
+    lm = flow_lm_spec(cfg)
+    n_lm = count_params(lm) - 2 * 128 - 1024 * 32  # buffers `freqs` and speaker_proj_weight are not in the count
+    assert abs(n_lm / 1e6 - 89.41) < 0.02, n_lm
+    assert abs(count_params(mimi_decode_spec(cfg)) / 1e6 - 10.31) < 0.01
+    assert len(state_dict_spec(named_config("24l"))) > len(state_dict_spec(cfg))
+
+
+def test_generator_is_deterministic_and_name_keyed():
+    a = generate_tensor("flow_lm.input_linear.weight", (1024, 32), 0)
+    b = generate_tensor("flow_lm.input_linear.weight", (1024, 32), 0)
+    c = generate_tensor("flow_lm.input_linear.weight", (1024, 32), 1)
+    d = generate_tensor("flow_lm.other.weight", (1024, 32), 0)
+    assert np.array_equal(a, b) and not np.array_equal(a, c) and not np.array_equal(a, d)
+    assert a.dtype == np.float32 and abs(float(a.std()) - (3.0 / 32) ** 0.5 / 3 ** 0.5) < 0.01
+
+
+def test_wav_writer(tmp_path):
+    from pocket_tts_amd.main import write_wav_stream
+
+    chunks = [torch.full((1920,), 0.5), torch.full((1920,), -2.0)]
+    n = write_wav_stream(str(tmp_path / "a.wav"), iter(chunks), 24000)
+    assert n == 2 * 1920 + 4800
+    with wave.open(str(tmp_path / "a.wav"), "rb") as w:
+        assert (w.getnchannels(), w.getframerate(), w.getsampwidth(), w.getnframes()) == (1, 24000, 2, n)
+        x = np.frombuffer(w.readframes(n), dtype=np.int16)
+    assert x[0] == 16383 and x[1920] == -32767 and np.all(x[-4800:] == 0)
