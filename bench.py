@@ -250,7 +250,7 @@ def main():
                 "workload": f"{args.config}: batch {args.batch} concurrent utterances/GPU, voice KV {args.voice_len} + "
                             f"text {args.text_len} tokens, {args.frames} frames (10 s) each, temp {args.temp}, "
                             f"lsd_decode_steps 1; per utterance: state clone + text prefill + FlowLM step + Mimi "
-                            f"decode per frame, one hipGraph per step with two parallel branches (FlowLM step t+1 || codec frame t), PCM written straight into pinned host memory",
+                            f"decode per frame, hipGraph per FlowLM step and per codec frame on two streams (step t+1 overlaps frame t), PCM written straight into pinned host memory",
                 "batch_per_gpu": args.batch,
                 "parallelism": f"replicas x{world} (no collective on the data path)",
             },

@@ -240,7 +240,7 @@ def test_pipelined_graph_matches_eager():
         pcm = eng.mimi_decode(ms, o)
         torch.cuda.synchronize()
         ref.append(pcm.cpu().numpy().copy())
-    for mode in ("fork", "hostsync"):
+    for mode in ("events", "fork", "hostsync"):
         _run_pipeline_mode(eng, mode, B, Tp, ns, emb, ref)
 
 
