@@ -59,6 +59,7 @@ struct Lin {  // one packed weight matrix
   float *w = nullptr, *bias = nullptr;
   int N = 0, NT = 0, C = 0, CF = 0, ntaps = 1, KF = 0;
   int cout = 0, stride = 0;  // transposed-conv view
+  float *ln_s = nullptr, *ln_c = nullptr;  // LayerNorm folded into this matrix (PRE_LNFOLD)
   size_t bytes() const { return (size_t)NT * KF * 1024; }
 };
 
@@ -194,7 +195,7 @@ struct PackPart { std::string w, b; int N; };
 
 // packs one or several [N_i][C][ntaps] matrices (stacked along N) into one Lin
 static int pack_lin(ptts_engine *e, Lin *L, const std::vector<PackPart> &parts, int C, int ntaps, int mode = 0,
-                    int cout = 0, int stride = 0) {
+                    int cout = 0, int stride = 0, const std::string &ln_w = "", const std::string &ln_b = "") {
   if (C % 16) return fail(-4, "channel count must be a multiple of 16: " + parts[0].w);
   int ntot = 0;
   for (auto &p : parts) ntot += cdiv(p.N, 16);
@@ -209,6 +210,18 @@ static int pack_lin(ptts_engine *e, Lin *L, const std::vector<PackPart> &parts, 
   CHK(dallocT(e, &L->w, (size_t)L->NT * L->KF * 256));
   bool any_bias = false;
   for (auto &p : parts) any_bias |= !p.b.empty();
+  const float *gam = nullptr, *bet = nullptr;
+  if (!ln_w.empty()) {
+    // fold the preceding LayerNorm: gain into the weights, mean / bias terms into two per-row vectors
+    int err = 0;
+    const ptts_tensor *tg = find_tensor(e, ln_w, C, &err), *tb = find_tensor(e, ln_b, C, &err);
+    if (!tg || !tb) return err;
+    gam = tg->d_data;
+    bet = tb->d_data;
+    CHK(dallocT(e, &L->ln_s, (size_t)L->NT * 16));
+    CHK(dallocT(e, &L->ln_c, (size_t)L->NT * 16));
+    any_bias = false;  // the bias is absorbed into ln_c
+  }
   if (any_bias) CHK(dallocT(e, &L->bias, (size_t)L->NT * 16));
   int nt_off = 0;
   for (auto &p : parts) {
@@ -218,7 +231,16 @@ static int pack_lin(ptts_engine *e, Lin *L, const std::vector<PackPart> &parts, 
     int nt = cdiv(p.N, 16);
     long total = (long)nt * L->KF * 256;
     pack_weight_kernel<<<cdiv(total, 256), 256, 0, e->stream>>>(t->d_data, L->w, p.N, C, ntaps, mode, cout, stride,
-                                                                nt_off, L->KF, total);
+                                                                nt_off, L->KF, total, gam);
+    if (gam) {
+      const float *bsrc = nullptr;
+      if (!p.b.empty()) {
+        const ptts_tensor *tb2 = find_tensor(e, p.b, p.N, &err);
+        if (!tb2) return err;
+        bsrc = tb2->d_data;
+      }
+      fold_ln_kernel<<<p.N, 64, 0, e->stream>>>(t->d_data, gam, bet, bsrc, L->ln_s, L->ln_c, p.N, C, nt_off * 16);
+    }
     if (any_bias) {
       const float *bsrc = nullptr;
       if (!p.b.empty()) {
@@ -244,9 +266,9 @@ static int pack_tr_layer(ptts_engine *e, TrLayer *T, const std::string &p, int d
     CHK(copy_vec(e, p + ".layer_scale_1.scale", d, &T->ls1));
     CHK(copy_vec(e, p + ".layer_scale_2.scale", d, &T->ls2));
   }
-  CHK(pack_lin(e, &T->qkv, {{p + ".self_attn.in_proj.weight", "", 3 * d}}, d, 1));
+  CHK(pack_lin(e, &T->qkv, {{p + ".self_attn.in_proj.weight", "", 3 * d}}, d, 1, 0, 0, 0, p + ".norm1.weight", p + ".norm1.bias"));
   CHK(pack_lin(e, &T->out, {{p + ".self_attn.out_proj.weight", "", d}}, d, 1));
-  CHK(pack_lin(e, &T->ff1, {{p + ".linear1.weight", "", ff}}, d, 1));
+  CHK(pack_lin(e, &T->ff1, {{p + ".linear1.weight", "", ff}}, d, 1, 0, 0, 0, p + ".norm2.weight", p + ".norm2.bias"));
   CHK(pack_lin(e, &T->ff2, {{p + ".linear2.weight", "", d}}, ff, 1));
   return 0;
 }
@@ -270,7 +292,7 @@ static void launch_cfg(hipStream_t st, const GemmArgs &a, int pre) {
   dim3 block(64 * WK * WN * WM);
   switch (pre) {
     case PRE_NONE: gemm_kernel<TN, TM, WK, WN, WM, PRE_NONE><<<grid, block, 0, st>>>(a); break;
-    case PRE_ELU: gemm_kernel<TN, TM, WK, WN, WM, PRE_ELU><<<grid, block, 0, st>>>(a); break;
+    case PRE_LNFOLD: gemm_kernel<TN, TM, WK, WN, WM, PRE_LNFOLD><<<grid, block, 0, st>>>(a); break;
     default: gemm_kernel<TN, TM, WK, WN, WM, PRE_ADDSILU><<<grid, block, 0, st>>>(a); break;
   }
 }
@@ -303,7 +325,7 @@ static void launch_gemm(hipStream_t st, const GemmArgs &a, int pre) {
   double bytes = 4.0 * (N * K + M * (double)a.CF * 16 + M * N);
   if (a.epi == EPI_RES || a.epi == EPI_GATE) bytes += 4.0 * M * N;
   const int cfg = pick_cfg(a);
-  ProfScope ps(st, std::string(kCfgName[cfg]) + (pre == PRE_NONE ? "" : pre == PRE_ELU ? "+elu" : "+addsilu"), bytes, 2.0 * M * N * K);
+  ProfScope ps(st, std::string(kCfgName[cfg]) + (pre == PRE_NONE ? "" : pre == PRE_LNFOLD ? "+ln" : "+addsilu"), bytes, 2.0 * M * N * K);
   switch (cfg) {
     case 0: launch_cfg<1, 1, 8, 1, 1>(st, a, pre); break;
     case 1: launch_cfg<1, 2, 8, 1, 1>(st, a, pre); break;
@@ -321,6 +343,9 @@ static GemmArgs mk_gemm(const Lin &L, const float *X, int XF, int MT, int M) {
   memset(&a, 0, sizeof(a));
   a.W = L.w;
   a.bias = L.bias;
+  a.ln_s = L.ln_s;
+  a.ln_c = L.ln_c;
+  a.ln_eps = 1e-5f;  // nn.LayerNorm(eps=1e-5): mimi_transformer.py:26-27, flow_lm.py:89
   a.NT = L.NT;
   a.KF = L.KF;
   a.CF = L.CF;
@@ -373,14 +398,13 @@ static void run_tr_layer(hipStream_t st, const TrLayer &T, const TrCtx &c) {
   const int DF = c.D / 16;
   const std::string tg(c.tag);
   std::string s1 = tg + ".ln1", s2 = tg + ".qkv", s3 = tg + ".attn", s4 = tg + ".out", s5 = tg + ".ln2", s6 = tg + ".ff1", s7 = tg + ".ff2";
-  SITE(s1.c_str());
-  launch_ln(st, c.x_in, 0, DF, c.h, DF, T.ln1_w, T.ln1_b, nullptr, nullptr, 0, DF, 1e-5f, c.MT, nullptr);
+  // norm1 is folded into the QKV projection, norm2 into linear1 (PRE_LNFOLD): no LayerNorm launches
   SITE(s2.c_str());
-  GemmArgs a = mk_gemm(T.qkv, c.h, DF, c.MT, c.M);
+  GemmArgs a = mk_gemm(T.qkv, c.x_in, DF, c.MT, c.M);
   a.epi = EPI_QKV;
   a.Q = c.q; a.Kc = c.Kc; a.Vc = c.Vc; a.offset = c.offset; a.rope = c.rope;
   a.H = c.H; a.Tq = c.Tq; a.QB = c.QB; a.cap = c.cap; a.ring = c.ring;
-  launch_gemm(st, a, PRE_NONE);
+  launch_gemm(st, a, PRE_LNFOLD);
   AttnArgs at;
   at.Q = c.q; at.Kc = c.Kc; at.Vc = c.Vc; at.offset = c.offset; at.H = c.H; at.Tq = c.Tq; at.QB = c.QB;
   at.cap = c.cap; at.ring = c.ring; at.ctx = c.ctx; at.splits = c.splits; at.part = c.part; at.Y = c.ao; at.YF = DF;
@@ -399,12 +423,10 @@ static void run_tr_layer(hipStream_t st, const TrLayer &T, const TrCtx &c) {
   a = mk_gemm(T.out, c.ao, DF, c.MT, c.M);
   a.epi = EPI_RES; a.R = c.x_in; a.RF = DF; a.Y = c.x; a.YF = DF; a.ls = T.ls1;
   launch_gemm(st, a, PRE_NONE);
-  SITE(s5.c_str());
-  launch_ln(st, c.x, 0, DF, c.h, DF, T.ln2_w, T.ln2_b, nullptr, nullptr, 0, DF, 1e-5f, c.MT, nullptr);
   SITE(s6.c_str());
-  a = mk_gemm(T.ff1, c.h, DF, c.MT, c.M);
+  a = mk_gemm(T.ff1, c.x, DF, c.MT, c.M);
   a.epi = EPI_STORE; a.act = ACT_GELU; a.Y = c.ff; a.YF = c.FF / 16;
-  launch_gemm(st, a, PRE_NONE);
+  launch_gemm(st, a, PRE_LNFOLD);
   SITE(s7.c_str());
   a = mk_gemm(T.ff2, c.ff, c.FF / 16, c.MT, c.M);
   a.epi = EPI_RES; a.R = c.x; a.RF = DF; a.Y = c.x_out; a.YF = DF; a.Ydstride = c.out_ds; a.par = c.par; a.ls = T.ls2;
@@ -452,7 +474,8 @@ extern "C" int ptts_create(const ptts_config *cfg, const ptts_tensor *tensors, i
   CHK(copy_vec(e, p + "out_norm.bias", D, &e->outnorm_b));
   std::string f = p + "flow_net.";
   // head = [cond_embed ; out_eos]: both read the out_norm output (flow_lm.py:129, mlp.py:209)
-  CHK(pack_lin(e, &e->head, {{f + "cond_embed.weight", f + "cond_embed.bias", FD}, {p + "out_eos.weight", p + "out_eos.bias", 1}}, D, 1));
+  CHK(pack_lin(e, &e->head, {{f + "cond_embed.weight", f + "cond_embed.bias", FD}, {p + "out_eos.weight", p + "out_eos.bias", 1}}, D, 1,
+               0, 0, 0, p + "out_norm.weight", p + "out_norm.bias"));
   {
     std::vector<PackPart> parts;
     for (int i = 0; i < c.flow_depth; ++i) {
@@ -828,13 +851,11 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
   a.Y = sc.x; a.YF = DF;
   launch_gemm(st, a, PRE_NONE);
   lm_layers(st, e, s, sc, B, 1);
-  SITE("lm.out_norm");
-  launch_ln(st, sc.x, 0, DF, s->c, DF, e->outnorm_w, e->outnorm_b, nullptr, nullptr, 0, DF, 1e-5f, MT, nullptr);
-  SITE("flow.head");
-  a = mk_gemm(e->head, s->c, DF, MT, B);
+  SITE("flow.head");  // out_norm is folded into [cond_embed ; out_eos]
+  a = mk_gemm(e->head, sc.x, DF, MT, B);
   a.epi = EPI_HEAD; a.Y = s->ce; a.YF = FDF; a.head_nt = FDF; a.eos_thr = eos_thr;
   a.eos_logit = s->eos_logit; a.is_eos = s->is_eos;
-  launch_gemm(st, a, PRE_NONE);
+  launch_gemm(st, a, PRE_LNFOLD);
   const int AF = e->adaln.NT;
   for (int i = 0; i < lsd_steps; ++i) {
     // all AdaLN modulations of the step in one GEMM on silu(t_emb + cond)  (mlp.py:107,127,210)
@@ -1207,7 +1228,6 @@ extern "C" int64_t ptts_debug_read(ptts_engine *e, void *state, int32_t is_mimi,
   if (!is_mimi) {
     ptts_lm_state *s = (ptts_lm_state *)state;
     if (n == "x") { src = s->dec.x; M = s->B; K = c.d_model; }
-    else if (n == "cond") { src = s->c; M = s->B; K = c.d_model; }
     else if (n == "ce") { src = s->ce; M = s->B; K = c.flow_dim; }
     else if (n == "fx") { src = s->fx; M = s->B; K = c.flow_dim; }
     else if (n == "prefill_x") { src = s->pre.x; M = s->pre.MT * 16; K = c.d_model; }

@@ -27,7 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PTTS_ABLATE 0
 #endif
 
-enum { PRE_NONE = 0, PRE_ELU = 1, PRE_ADDSILU = 2 };
+enum { PRE_NONE = 0, PRE_ELU = 1, PRE_ADDSILU = 2, PRE_LNFOLD = 3 };
 enum { EPI_STORE = 0, EPI_RES, EPI_GATE, EPI_QKV, EPI_HEAD, EPI_LATENT, EPI_CONVTR, EPI_PCM };
 enum { ACT_NONE = 0, ACT_GELU, ACT_SILU, ACT_ELU };
 
@@ -61,6 +61,11 @@ struct GemmArgs {
   int XF, MT, M, T;  // M = valid rows, T = rows per sequence (multiple of 16 when ntaps > 1)
   const int *par;    // device frame counter (parity = *par & 1) or null
   const float *prevec;  // PRE_ADDSILU: per-k vector
+  // PRE_LNFOLD: LayerNorm folded into this GEMM.  W is packed with the LN gain multiplied in (W' = W diag(g)),
+  // ln_s[n] = sum_k W'[n][k], ln_c[n] = sum_k W[n][k] beta[k] (+ bias); the kernel accumulates sum(x), sum(x^2)
+  // per row from the X fragments it loads anyway and finishes  y = rstd (W'x - mean ln_s) + ln_c.
+  const float *ln_s, *ln_c;
+  float ln_eps;
   int epi, act;
   // output FM view
   float *Y;
@@ -213,6 +218,9 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
   const float *Xp = a.X + (par ^ 1) * a.Xdstride;
   const int k0 = (a.KF * wk) / WK, k1 = (a.KF * (wk + 1)) / WK;
 
+  float sx[TM], sxx[TM];  // PRE_LNFOLD row statistics (this lane's row of each m-tile, its k-groups only)
+#pragma unroll
+  for (int j = 0; j < TM; ++j) sx[j] = sxx[j] = 0.f;
   // a lone tile per wave would be one dependent MFMA chain: give it two accumulators (summed at the end)
   constexpr int NACC = (TN * TM == 1) ? 2 : 1;
   f32x4 acc[TN][TM][NACC];
@@ -284,6 +292,14 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
     for (int u = 0; u < UU; ++u) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) x[u][j] = pre4<PRE>(x[u][j], a.prevec, kf + u, lane);
+      if constexpr (PRE == PRE_LNFOLD) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const f32x4 v = x[u][j];
+          sx[j] += (v.x + v.y) + (v.z + v.w);
+          sxx[j] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+      }
       // k-step major: back-to-back MFMAs hit DIFFERENT accumulators, so none waits out the 40-cycle
       // dependent-accumulator latency of v_mfma_f32_16x16x4_f32 (issue interval 32 cycles)
 #pragma unroll
@@ -342,16 +358,57 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
       accs[i][j] = acc[i][j][0];
       if constexpr (NACC == 2) accs[i][j] += acc[i][j][1];
     }
+  // PRE_LNFOLD: finish the row statistics.  Lanes l, l^16, l^32, l^48 hold the four k-groups of one row.
+  float mu[TM], rs[TM];
+  if constexpr (PRE == PRE_LNFOLD) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      sx[j] += __shfl_xor(sx[j], 16); sx[j] += __shfl_xor(sx[j], 32);
+      sxx[j] += __shfl_xor(sxx[j], 16); sxx[j] += __shfl_xor(sxx[j], 32);
+    }
+  }
+  auto ln_fix = [&](f32x4 v, int nt, int j) {
+    if constexpr (PRE == PRE_LNFOLD) {
+      const int n0 = 16 * nt + 4 * (lane >> 4);
+      const f32x4 s4 = *(const f32x4 *)(a.ln_s + n0), c4 = *(const f32x4 *)(a.ln_c + n0);
+      return (v - s4 * mu[j]) * rs[j] + c4;
+    } else {
+      return v;
+    }
+  };
   if constexpr (WK > 1) {
     // every wave parks its partial tiles in LDS; tile i*TM+j is then summed (fixed order) and finished by
     // wave (i*TM+j) % WK, so the epilogues of a workgroup run on several SIMDs at once
     __shared__ f32x4 red[WK * WN * WM * TN * TM * 64];
+    __shared__ float red_st[(PRE == PRE_LNFOLD) ? WK * WN * WM * TM * 32 : 1];
     const int grp = wave / WK;  // (wn, wm) group
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
       for (int j = 0; j < TM; ++j) red[(((wk * WN * WM + grp) * TN + i) * TM + j) * 64 + lane] = accs[i][j];
+    if constexpr (PRE == PRE_LNFOLD) {
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          red_st[(((wk * WN * WM + grp) * TM + j) * 16 + lane) * 2 + 0] = sx[j];
+          red_st[(((wk * WN * WM + grp) * TM + j) * 16 + lane) * 2 + 1] = sxx[j];
+        }
+      }
+    }
     __syncthreads();
+    if constexpr (PRE == PRE_LNFOLD) {
+      const float invK = 1.0f / (float)(a.KF * 16);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        float t0 = 0.f, t1 = 0.f;
+        for (int s2 = 0; s2 < WK; ++s2) {
+          t0 += red_st[(((s2 * WN * WM + grp) * TM + j) * 16 + (lane & 15)) * 2 + 0];
+          t1 += red_st[(((s2 * WN * WM + grp) * TM + j) * 16 + (lane & 15)) * 2 + 1];
+        }
+        mu[j] = t0 * invK;
+        rs[j] = 1.0f / sqrtf(fmaxf(t1 * invK - mu[j] * mu[j], 0.f) + a.ln_eps);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -359,14 +416,22 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
         if ((i * TM + j) % WK != wk) continue;
         f32x4 sum = red[(((0 * WN * WM + grp) * TN + i) * TM + j) * 64 + lane];
         for (int s2 = 1; s2 < WK; ++s2) sum += red[(((s2 * WN * WM + grp) * TN + i) * TM + j) * 64 + lane];
-        if (nt0 + i < a.NT && mt0 + j < a.MT) gemm_epilogue(a, sum, nt0 + i, mt0 + j, lane, par);
+        if (nt0 + i < a.NT && mt0 + j < a.MT) gemm_epilogue(a, ln_fix(sum, nt0 + i, j), nt0 + i, mt0 + j, lane, par);
       }
   } else {
+    if constexpr (PRE == PRE_LNFOLD) {
+      const float invK = 1.0f / (float)(a.KF * 16);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        mu[j] = sx[j] * invK;
+        rs[j] = 1.0f / sqrtf(fmaxf(sxx[j] * invK - mu[j] * mu[j], 0.f) + a.ln_eps);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
       for (int j = 0; j < TM; ++j)
-        if (nt0 + i < a.NT && mt0 + j < a.MT) gemm_epilogue(a, accs[i][j], nt0 + i, mt0 + j, lane, par);
+        if (nt0 + i < a.NT && mt0 + j < a.MT) gemm_epilogue(a, ln_fix(accs[i][j], nt0 + i, j), nt0 + i, mt0 + j, lane, par);
   }
   (void)NW;
 }
@@ -378,7 +443,7 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
 // dst[nt][tap*CF + cf][lane][j4] = W[n = 16nt + (lane&15)][c = 16cf + 4(lane>>4) + j4][tap]
 // ---------------------------------------------------------------------------------------------
 __global__ void pack_weight_kernel(const float *src, float *dst, int N, int C, int ntaps, int mode, int cout,
-                                   int stride, int nt_off, int KF, long total) {
+                                   int stride, int nt_off, int KF, long total, const float *colscale) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   int j4 = i & 3;
@@ -394,6 +459,7 @@ __global__ void pack_weight_kernel(const float *src, float *dst, int N, int C, i
   if (n < N) {
     if (mode == 0) {
       v = src[((size_t)n * C + c) * ntaps + tap];
+      if (colscale) v *= colscale[c];
     } else {
       int j = n / cout, nn = n - j * cout;
       int kidx = tap == 1 ? j : j + stride;
@@ -401,6 +467,24 @@ __global__ void pack_weight_kernel(const float *src, float *dst, int N, int C, i
     }
   }
   dst[((size_t)(nt + nt_off) * KF) * 256 + (size_t)kf * 256 + lane * 4 + j4] = v;
+}
+
+// LayerNorm folding constants of one Linear [N][K]: s[n] = sum_k W[n][k] g[k], c[n] = sum_k W[n][k] b[k] + bias[n].
+// One wave per output row; load time only.
+__global__ void fold_ln_kernel(const float *W, const float *g, const float *b, const float *bias, float *s_out,
+                               float *c_out, int N, int K, int n_off) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f, c = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = W[(size_t)n * K + k];
+    s += w * g[k];
+    c += w * b[k];
+  }
+  for (int o = 32; o; o >>= 1) { s += __shfl_xor(s, o); c += __shfl_xor(c, o); }
+  if (lane == 0) {
+    s_out[n_off + n] = s;
+    c_out[n_off + n] = c + (bias ? bias[n] : 0.f);
+  }
 }
 
 __global__ void pack_bias_kernel(const float *src, float *dst, int N, int mode, int cout, int n_off, int Npad) {

@@ -48,7 +48,7 @@ static void test_gemm(int M, int N, int K, int cfg) {
   float *yfm = dzero<float>((size_t)MT * NT * 256), *dY = dzero<float>((size_t)M * NT * 16);
   to_fm_kernel<<<cdiv((long)MT * KF * 64, 256), 256>>>(dX, xfm, M, K, MT);
   long tot = (long)NT * KF * 256;
-  pack_weight_kernel<<<cdiv(tot, 256), 256>>>(dW, wp, N, K, 1, 0, 0, 0, 0, KF, tot);
+  pack_weight_kernel<<<cdiv(tot, 256), 256>>>(dW, wp, N, K, 1, 0, 0, 0, 0, KF, tot, nullptr);
   pack_bias_kernel<<<cdiv(NT * 16, 256), 256>>>(db, bp, N, 0, 0, 0, NT * 16);
   GemmArgs a; memset(&a, 0, sizeof(a));
   a.W = wp; a.bias = bp; a.NT = NT; a.KF = KF; a.CF = KF; a.ntaps = 1; a.X = xfm; a.XF = KF; a.MT = MT; a.M = M; a.T = 16;
@@ -91,7 +91,7 @@ static void test_conv(int B, int T, int C, int N, int ntaps, int cfg) {
   to_fm_kernel<<<cdiv((long)MT * CF * 64, 256), 256>>>(dXc, xfm + xs, M, C, MT);
   to_fm_kernel<<<cdiv((long)MT * CF * 64, 256), 256>>>(dXp, xfm, M, C, MT);
   long tot = (long)NT * KF * 256;
-  pack_weight_kernel<<<cdiv(tot, 256), 256>>>(dW, wp, N, C, ntaps, 0, 0, 0, 0, KF, tot);
+  pack_weight_kernel<<<cdiv(tot, 256), 256>>>(dW, wp, N, C, ntaps, 0, 0, 0, 0, KF, tot, nullptr);
   pack_bias_kernel<<<cdiv(NT * 16, 256), 256>>>(db, bp, N, 0, 0, 0, NT * 16);
   GemmArgs a; memset(&a, 0, sizeof(a));
   a.W = wp; a.bias = bp; a.NT = NT; a.KF = KF; a.CF = CF; a.ntaps = ntaps; a.X = xfm; a.Xdstride = xs; a.XF = CF; a.MT = MT; a.M = M; a.T = T; a.par = par;
@@ -107,6 +107,52 @@ static void test_conv(int B, int T, int C, int N, int ntaps, int cfg) {
   for (int m = 0; m < M; ++m) for (int n = 0; n < N; ++n) g2[m * N + n] = got[(size_t)m * NT * 16 + n];
   char nm[128]; snprintf(nm, sizeof nm, "conv B=%d T=%d C=%d N=%d k=%d cfg=%d", B, T, C, N, ntaps, cfg);
   report(nm, maxerr(g2, Y), 2e-3);
+}
+
+template <int TN, int TM, int WK, int WN, int WM>
+static void run_gemm_ln(const GemmArgs &a) {
+  dim3 grid(cdiv(a.NT, TN * WN), cdiv(a.MT, TM * WM));
+  gemm_kernel<TN, TM, WK, WN, WM, PRE_LNFOLD><<<grid, 64 * WK * WN * WM>>>(a);
+  CK(hipDeviceSynchronize());
+}
+
+// LayerNorm folded into the GEMM: Y = LN(X; g, b, eps) W^T + bias
+static void test_gemm_lnfold(int M, int N, int K, int cfg) {
+  std::vector<float> X(M * K), W(N * K), g(K), b(K), bias(N), Y(M * N);
+  for (auto &v : X) v = frand() * 2 + 0.3f; for (auto &v : W) v = frand(); for (auto &v : g) v = 1 + 0.2f * frand();
+  for (auto &v : b) v = 0.2f * frand(); for (auto &v : bias) v = frand();
+  for (int m = 0; m < M; ++m) {
+    double mu = 0, var = 0; for (int k = 0; k < K; ++k) mu += X[m * K + k]; mu /= K;
+    for (int k = 0; k < K; ++k) var += (X[m * K + k] - mu) * (X[m * K + k] - mu); var /= K;
+    for (int n = 0; n < N; ++n) {
+      double s = bias[n];
+      for (int k = 0; k < K; ++k) s += ((X[m * K + k] - mu) / std::sqrt(var + 1e-5) * g[k] + b[k]) * W[n * K + k];
+      Y[m * N + n] = (float)s;
+    }
+  }
+  int MT = cdiv(M, 16), NT = cdiv(N, 16), KF = K / 16;
+  float *dX = dev(X), *dW = dev(W), *dg = dev(g), *db = dev(b), *dbias = dev(bias);
+  float *xfm = dzero<float>((size_t)MT * KF * 256), *wp = dzero<float>((size_t)NT * KF * 256);
+  float *ls = dzero<float>(NT * 16), *lc = dzero<float>(NT * 16);
+  float *yfm = dzero<float>((size_t)MT * NT * 256), *dY = dzero<float>((size_t)M * NT * 16);
+  to_fm_kernel<<<cdiv((long)MT * KF * 64, 256), 256>>>(dX, xfm, M, K, MT);
+  long tot = (long)NT * KF * 256;
+  pack_weight_kernel<<<cdiv(tot, 256), 256>>>(dW, wp, N, K, 1, 0, 0, 0, 0, KF, tot, dg);
+  fold_ln_kernel<<<N, 64>>>(dW, dg, db, dbias, ls, lc, N, K, 0);
+  GemmArgs a; memset(&a, 0, sizeof(a));
+  a.W = wp; a.NT = NT; a.KF = KF; a.CF = KF; a.ntaps = 1; a.X = xfm; a.XF = KF; a.MT = MT; a.M = M; a.T = 16;
+  a.ln_s = ls; a.ln_c = lc; a.ln_eps = 1e-5f; a.epi = EPI_STORE; a.Y = yfm; a.YF = NT;
+  if (cfg == 0) run_gemm_ln<1, 1, 8, 1, 1>(a);
+  else if (cfg == 2) run_gemm_ln<1, 4, 8, 1, 1>(a);
+  else if (cfg == 3) run_gemm_ln<2, 4, 1, 2, 2>(a);
+  else run_gemm_ln<2, 4, 4, 1, 1>(a);
+  from_fm_kernel<<<cdiv((long)M * NT * 4, 256), 256>>>(yfm, dY, M, NT * 16, NT, 0);
+  CK(hipDeviceSynchronize());
+  auto got = host(dY, (size_t)M * NT * 16);
+  std::vector<float> g2(M * N);
+  for (int m = 0; m < M; ++m) for (int n = 0; n < N; ++n) g2[m * N + n] = got[(size_t)m * NT * 16 + n];
+  char nm[128]; snprintf(nm, sizeof nm, "gemm+LNfold M=%d N=%d K=%d cfg=%d", M, N, K, cfg);
+  report(nm, maxerr(g2, Y), 2e-4 * std::sqrt((double)K / 64));
 }
 
 static void test_ln(int M, int K) {
@@ -187,6 +233,8 @@ int main() {
   test_conv(5, 48, 32, 70, 2, 3);
   test_conv(4, 96, 16, 1, 3, 5);
   test_ln(5, 128); test_ln(40, 512); test_ln(16, 1024);
+  test_gemm_lnfold(3, 48, 128, 0); test_gemm_lnfold(50, 96, 1024, 2); test_gemm_lnfold(200, 130, 512, 3);
+  test_gemm_lnfold(130, 64, 1024, 7);
   test_attn(4, 1, 0, 0, 0, 1);
   test_attn(4, 1, 37, 0, 0, 1);
   test_attn(4, 1, 200, 0, 0, 5);
