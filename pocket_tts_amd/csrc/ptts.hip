@@ -297,13 +297,23 @@ static void launch_cfg(hipStream_t st, const GemmArgs &a, int pre) {
   }
 }
 
-// Tile selection.  K-split configs (TM row tiles per wave, 8 waves split K, LDS-reduced) give NT x ceil(MT/TM)
+template <int BMT, int BNT>
+static void launch_lds(hipStream_t st, const GemmArgs &a, int pre) {
+  dim3 grid(cdiv(a.NT, BNT), cdiv(a.MT, BMT));
+  if (pre == PRE_LNFOLD) gemm_lds_kernel<BMT, BNT, 2, PRE_LNFOLD><<<grid, 256, 0, st>>>(a);
+  else gemm_lds_kernel<BMT, BNT, 2, PRE_NONE><<<grid, 256, 0, st>>>(a);
+}
+
+// Tile selection.  K-split configs (TM row tiles per wave, 4 waves split K, LDS-reduced) give NT x ceil(MT/TM)
 // workgroups and stream each weight fragment ceil(MT/TM) times (L2 / Infinity Cache absorb the re-reads);
 // the 2-D tiled configs amortise operand loads over 2x4 tiles per wave but need a large grid to fill 256 CUs.
 // Pick the K-split row-tile count TM that still yields >= ~256 workgroups, and use 2-D tiles only when
 // their grid is large.
 static int pick_cfg(const GemmArgs &a) {
   const long tiled = (long)cdiv(a.NT, 4) * cdiv(a.MT, 8);
+  // many rows (codec convs at batch >= 16): LDS-staged kernel, each operand fragment DMA'd once per workgroup
+  // (tests/hip/sweep_gemm.hip: 5-12 % faster than the register-staged tiles on these shapes)
+  if (a.MT >= 256 && a.NT >= 4 && a.KF % 2 == 0 && a.epi != EPI_QKV) return a.NT >= 8 ? 8 : 9;
   if (a.MT > 4 && tiled >= 192) return a.NT >= 4 ? 3 : a.NT >= 2 ? 4 : 5;
   // few output tiles but a long K (Mimi FFN2 / conv k7 / out_proj at moderate batch): 2x4 tiles per wave,
   // the 4 waves of a workgroup split K -> 4x the workgroups of the 2-D tiling at the same operand reuse
@@ -316,8 +326,9 @@ static int pick_cfg(const GemmArgs &a) {
   while (tm > 1 && (long)a.NT * cdiv(a.MT, tm) < 256) tm >>= 1;
   return tm == 4 ? 2 : tm == 2 ? 1 : 0;
 }
-static const char *const kCfgName[8] = {"gemm<1,1,8,1,1>", "gemm<1,2,8,1,1>", "gemm<1,4,8,1,1>", "gemm<2,4,1,2,2>",
-                                        "gemm<2,4,1,1,4>", "gemm<1,4,1,1,4>", "gemm<1,1,1,1,4>", "gemm<2,4,4,1,1>"};
+static const char *const kCfgName[10] = {"gemm<1,1,8,1,1>", "gemm<1,2,4,1,1>", "gemm<1,4,4,1,1>", "gemm<2,4,1,2,2>",
+                                        "gemm<2,4,1,1,4>", "gemm<1,4,1,1,4>", "gemm<1,1,1,1,4>", "gemm<2,4,4,1,1>",
+                                         "gemm_lds<4,8,2>", "gemm_lds<4,4,2>"};
 
 static void launch_gemm(hipStream_t st, const GemmArgs &a, int pre) {
   // algorithmic traffic: weights once + input rows once (x taps re-read from cache, not counted) + output
@@ -327,14 +338,17 @@ static void launch_gemm(hipStream_t st, const GemmArgs &a, int pre) {
   const int cfg = pick_cfg(a);
   ProfScope ps(st, std::string(kCfgName[cfg]) + (pre == PRE_NONE ? "" : pre == PRE_LNFOLD ? "+ln" : "+addsilu"), bytes, 2.0 * M * N * K);
   switch (cfg) {
-    case 0: launch_cfg<1, 1, 8, 1, 1>(st, a, pre); break;
-    case 1: launch_cfg<1, 2, 8, 1, 1>(st, a, pre); break;
-    case 2: launch_cfg<1, 4, 8, 1, 1>(st, a, pre); break;
+    case 0: launch_cfg<1, 1, 8, 1, 1>(st, a, pre); break;  // 8 waves: most bytes in flight per CU for cold weights
+    // TM >= 2: 4-wave K split measured >= 8-wave (tests/hip/sweep_gemm.hip)
+    case 1: launch_cfg<1, 2, 4, 1, 1>(st, a, pre); break;
+    case 2: launch_cfg<1, 4, 4, 1, 1>(st, a, pre); break;
     case 3: launch_cfg<2, 4, 1, 2, 2>(st, a, pre); break;
     case 4: launch_cfg<2, 4, 1, 1, 4>(st, a, pre); break;
     case 5: launch_cfg<1, 4, 1, 1, 4>(st, a, pre); break;
     case 6: launch_cfg<1, 1, 1, 1, 4>(st, a, pre); break;
-    default: launch_cfg<2, 4, 4, 1, 1>(st, a, pre); break;
+    case 7: launch_cfg<2, 4, 4, 1, 1>(st, a, pre); break;
+    case 8: launch_lds<4, 8>(st, a, pre); break;
+    default: launch_lds<4, 4>(st, a, pre); break;
   }
 }
 

@@ -437,6 +437,142 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// LDS-staged variant for the large-M GEMMs of the codec (rows = sequences x time).  A workgroup of 4 waves
+// (2 x 2) owns BMT x BNT 16x16 tiles.  Per stage of KC k-fragments every operand fragment is copied ONCE per
+// workgroup by `global_load_lds_dwordx4` (1 KiB, wave-linear = exactly the FM / packed fragment image, no VGPRs),
+// then each wave reads its fragments with conflict-free ds_read_b128.  Two stages: the DMA of stage s+1 is in
+// flight while stage s feeds the MFMAs; one barrier per stage.
+// ---------------------------------------------------------------------------------------------
+#define GLDS16(gptr, lptr)                                                                      \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),      \
+                                   (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+template <int BMT, int BNT, int KC, int PRE>
+__global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
+  static_assert(BMT % 4 == 0 && BNT % 2 == 0, "tile shape");
+  constexpr int WMT = BMT / 2, WNT = BNT / 2;  // tiles per wave
+  constexpr int NX = BMT * KC, NFRAG = (BMT + BNT) * KC;
+  constexpr int XPW = BMT / 4;  // distinct m-tiles a loader wave touches (fragment f -> wave f % 4)
+  __shared__ f32x4 lds[2][NFRAG][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int mt0 = blockIdx.y * BMT, nt0 = blockIdx.x * BNT;
+  const int par = a.par ? (*a.par & 1) : 0;
+  const float *Xc = a.X + par * a.Xdstride;
+  const float *Xp = a.X + (par ^ 1) * a.Xdstride;
+  const int halo = a.ntaps - 1;
+
+  // loader bookkeeping: this wave copies X fragments of m-tiles {wave, wave+4, ..} and W fragments f % 4 == wave
+  int l_mt[XPW], l_t[XPW], l_bT[XPW];
+#pragma unroll
+  for (int q = 0; q < XPW; ++q) {
+    int mt = mt0 + wave + 4 * q;
+    mt = mt < a.MT ? mt : a.MT - 1;
+    l_mt[q] = mt;
+    int row = 16 * mt + (lane & 15);
+    int t = a.ntaps > 1 ? row % a.T : 0;
+    l_t[q] = t;
+    l_bT[q] = row - t;
+  }
+  auto issue = [&](int kf0, int buf) {
+    // X fragments: index kc * BMT + m, m = wave + 4q
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const int kf = kf0 + kc;
+      int tap = 0, cf = kf;
+      if (a.ntaps > 1) { tap = kf / a.CF; cf = kf - tap * a.CF; }
+#pragma unroll
+      for (int q = 0; q < XPW; ++q) {
+        const float *src;
+        if (a.ntaps == 1) {
+          src = Xc + (((size_t)l_mt[q] * a.XF + kf) * 64 + lane) * 4;
+        } else {
+          int ts = l_t[q] + tap - halo;
+          const float *base = ts >= 0 ? Xc : Xp;
+          int rr = l_bT[q] + (ts >= 0 ? ts : a.T + ts);
+          src = base + (((size_t)(rr >> 4) * a.XF + cf) * 64 + (lane & 48) + (rr & 15)) * 4;
+        }
+        GLDS16(src, &lds[buf][kc * BMT + wave + 4 * q][0]);
+      }
+    }
+    // W fragments: index NX + kc * BNT + n, distributed round-robin over the 4 waves
+#pragma unroll
+    for (int f = 0; f < BNT * KC; ++f) {
+      if ((f & 3) != wave) continue;
+      const int kc = f / BNT, n = f - kc * BNT;
+      int nt = nt0 + n;
+      nt = nt < a.NT ? nt : a.NT - 1;
+      GLDS16(a.W + ((size_t)nt * a.KF + kf0 + kc) * 256 + lane * 4, &lds[buf][NX + f][0]);
+    }
+  };
+
+  f32x4 acc[WNT][WMT];
+#pragma unroll
+  for (int i = 0; i < WNT; ++i)
+#pragma unroll
+    for (int j = 0; j < WMT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float sx[WMT], sxx[WMT];
+#pragma unroll
+  for (int j = 0; j < WMT; ++j) sx[j] = sxx[j] = 0.f;
+
+  const int nst = a.KF / KC;  // host guarantees KF % KC == 0
+  issue(0, 0);
+  for (int s = 0; s < nst; ++s) {
+    const int cur = s & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of stage s has landed
+    __syncthreads();                                   // ... everyone's has, and buffer cur^1 is free again
+    if (s + 1 < nst) issue((s + 1) * KC, cur ^ 1);
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      f32x4 x[WMT], w[WNT];
+#pragma unroll
+      for (int j = 0; j < WMT; ++j) x[j] = lds[cur][kc * BMT + wm * WMT + j][lane];
+#pragma unroll
+      for (int i = 0; i < WNT; ++i) w[i] = lds[cur][NX + kc * BNT + wn * WNT + i][lane];
+      if constexpr (PRE == PRE_LNFOLD) {
+#pragma unroll
+        for (int j = 0; j < WMT; ++j) {
+          sx[j] += (x[j].x + x[j].y) + (x[j].z + x[j].w);
+          sxx[j] += (x[j].x * x[j].x + x[j].y * x[j].y) + (x[j].z * x[j].z + x[j].w * x[j].w);
+        }
+      }
+#pragma unroll
+      for (int cidx = 0; cidx < 4; ++cidx)
+#pragma unroll
+        for (int i = 0; i < WNT; ++i)
+#pragma unroll
+          for (int j = 0; j < WMT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][cidx], x[j][cidx], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  float mu[WMT], rs[WMT];
+  if constexpr (PRE == PRE_LNFOLD) {
+    const float invK = 1.0f / (float)(a.KF * 16);
+#pragma unroll
+    for (int j = 0; j < WMT; ++j) {
+      sx[j] += __shfl_xor(sx[j], 16); sx[j] += __shfl_xor(sx[j], 32);
+      sxx[j] += __shfl_xor(sxx[j], 16); sxx[j] += __shfl_xor(sxx[j], 32);
+      mu[j] = sx[j] * invK;
+      rs[j] = 1.0f / sqrtf(fmaxf(sxx[j] * invK - mu[j] * mu[j], 0.f) + a.ln_eps);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < WNT; ++i)
+#pragma unroll
+    for (int j = 0; j < WMT; ++j) {
+      const int nt = nt0 + wn * WNT + i, mt = mt0 + wm * WMT + j;
+      if (nt >= a.NT || mt >= a.MT) continue;
+      f32x4 v = acc[i][j];
+      if constexpr (PRE == PRE_LNFOLD) {
+        const int n0 = 16 * nt + 4 * (lane >> 4);
+        v = (v - *(const f32x4 *)(a.ln_s + n0) * mu[j]) * rs[j] + *(const f32x4 *)(a.ln_c + n0);
+      }
+      gemm_epilogue(a, v, nt, mt, lane, par);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Weight packing (load time).  mode 0: Linear / Conv1d weight [N][C][ntaps] -> value(n, c, tap);
 // mode 1: ConvTranspose1d weight [C][cout][2s] viewed as a 2-tap conv with n' = j*cout + n:
 //         tap 1 (current input row) uses kernel index j, tap 0 (previous row) uses j + s.

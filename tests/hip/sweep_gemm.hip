@@ -34,8 +34,33 @@ static void run(std::vector<Res> &out, int M, int N, int K, int ntaps, int T) {
   char nm[64]; snprintf(nm, sizeof nm, "<%d,%d,%d,%d,%d>", TN, TM, WK, WN, WM);
   out.push_back({nm, us, (int)grid.x, (int)grid.y});
 }
+template <int BMT, int BNT, int KC>
+static void run_lds(std::vector<Res> &out, int M, int N, int K, int ntaps, int T) {
+  int MT = cdiv(M, 16), NT = cdiv(N, 16), CF = K / 16, KF = CF * ntaps;
+  if (KF % KC || BMT > 2 * MT || BNT > 2 * NT) return;
+  size_t wsz = (size_t)NT * KF * 256, xsz = (size_t)MT * CF * 256, ysz = (size_t)MT * NT * 256;
+  if ((wsz + 2 * xsz + ysz + 64) * 4 > ((size_t)3 << 30)) return;
+  GemmArgs a; memset(&a, 0, sizeof a);
+  a.W = g_buf; a.X = g_buf + wsz; a.Y = g_buf + wsz + 2 * xsz; a.Xdstride = ntaps > 1 ? xsz : 0;
+  a.par = ntaps > 1 ? (int *)(g_buf + wsz + 2 * xsz + ysz) : nullptr;
+  a.NT = NT; a.KF = KF; a.CF = CF; a.ntaps = ntaps; a.XF = CF; a.MT = MT; a.M = M; a.T = T; a.epi = EPI_STORE; a.YF = NT;
+  dim3 grid(cdiv(NT, BNT), cdiv(MT, BMT));
+  auto launch = [&] { gemm_lds_kernel<BMT, BNT, KC, PRE_NONE><<<grid, 256, 0, g_st>>>(a); };
+  for (int i = 0; i < 3; ++i) launch();
+  hipStreamSynchronize(g_st);
+  const int R = 20;
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < R; ++i) launch();
+  hipStreamSynchronize(g_st);
+  double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / R;
+  char nm[64]; snprintf(nm, sizeof nm, "LDS<%d,%d,%d>", BMT, BNT, KC);
+  out.push_back({nm, us, (int)grid.x, (int)grid.y});
+}
 static void sweep(const char *name, int M, int N, int K, int ntaps, int T) {
   std::vector<Res> r;
+  run_lds<8, 4, 2>(r, M, N, K, ntaps, T); run_lds<8, 8, 2>(r, M, N, K, ntaps, T); run_lds<4, 4, 2>(r, M, N, K, ntaps, T);
+  run_lds<8, 4, 4>(r, M, N, K, ntaps, T); run_lds<4, 4, 4>(r, M, N, K, ntaps, T); run_lds<8, 2, 2>(r, M, N, K, ntaps, T);
+  run_lds<4, 2, 2>(r, M, N, K, ntaps, T); run_lds<4, 8, 2>(r, M, N, K, ntaps, T);
   run<1, 1, 8, 1, 1>(r, M, N, K, ntaps, T); run<1, 2, 8, 1, 1>(r, M, N, K, ntaps, T); run<1, 4, 8, 1, 1>(r, M, N, K, ntaps, T);
   run<1, 1, 4, 1, 1>(r, M, N, K, ntaps, T); run<1, 2, 4, 1, 1>(r, M, N, K, ntaps, T); run<1, 4, 4, 1, 1>(r, M, N, K, ntaps, T);
   run<2, 4, 4, 1, 1>(r, M, N, K, ntaps, T); run<2, 4, 2, 1, 2>(r, M, N, K, ntaps, T); run<2, 2, 4, 1, 1>(r, M, N, K, ntaps, T);
@@ -51,7 +76,7 @@ static void sweep(const char *name, int M, int N, int K, int ntaps, int T) {
 int main() {
   hipStreamCreate(&g_st);
   hipMalloc(&g_buf, (size_t)3 << 30); hipMemset(g_buf, 0, (size_t)3 << 30);
-  const int Bs[] = {1, 4, 16, 64};
+  const int Bs[] = {16, 64};
   for (int B : Bs) {
     printf("---- batch %d\n", B);
     sweep("lm.qkv", B, 3072, 1024, 1, 16); sweep("lm.out", B, 1024, 1024, 1, 16);

@@ -53,7 +53,11 @@ static void test_gemm(int M, int N, int K, int cfg) {
   GemmArgs a; memset(&a, 0, sizeof(a));
   a.W = wp; a.bias = bp; a.NT = NT; a.KF = KF; a.CF = KF; a.ntaps = 1; a.X = xfm; a.XF = KF; a.MT = MT; a.M = M; a.T = 16;
   a.epi = EPI_STORE; a.Y = yfm; a.YF = NT;
-  if (cfg == 0) run_gemm<1, 1, 8, 1, 1>(a);
+  if (cfg >= 100) {
+    dim3 grid(cdiv(a.NT, cfg == 100 ? 4 : 8), cdiv(a.MT, 8));
+    if (cfg == 100) gemm_lds_kernel<8, 4, 2, PRE_NONE><<<grid, 256>>>(a); else gemm_lds_kernel<8, 8, 2, PRE_NONE><<<grid, 256>>>(a);
+    CK(hipDeviceSynchronize());
+  } else if (cfg == 0) run_gemm<1, 1, 8, 1, 1>(a);
   else if (cfg == 1) run_gemm<1, 2, 8, 1, 1>(a);
   else if (cfg == 2) run_gemm<1, 4, 8, 1, 1>(a);
   else if (cfg == 3) run_gemm<2, 4, 1, 2, 2>(a);
@@ -96,7 +100,11 @@ static void test_conv(int B, int T, int C, int N, int ntaps, int cfg) {
   GemmArgs a; memset(&a, 0, sizeof(a));
   a.W = wp; a.bias = bp; a.NT = NT; a.KF = KF; a.CF = CF; a.ntaps = ntaps; a.X = xfm; a.Xdstride = xs; a.XF = CF; a.MT = MT; a.M = M; a.T = T; a.par = par;
   a.epi = EPI_STORE; a.Y = yfm; a.YF = NT;
-  if (cfg == 0) run_gemm<1, 1, 8, 1, 1>(a);
+  if (cfg >= 100) {
+    dim3 grid(cdiv(a.NT, 4), cdiv(a.MT, cfg == 100 ? 8 : 4));
+    if (cfg == 100) gemm_lds_kernel<8, 4, 2, PRE_NONE><<<grid, 256>>>(a); else gemm_lds_kernel<4, 4, 2, PRE_NONE><<<grid, 256>>>(a);
+    CK(hipDeviceSynchronize());
+  } else if (cfg == 0) run_gemm<1, 1, 8, 1, 1>(a);
   else if (cfg == 2) run_gemm<1, 4, 8, 1, 1>(a);
   else if (cfg == 3) run_gemm<2, 4, 1, 2, 2>(a);
   else run_gemm<1, 4, 1, 1, 4>(a);
@@ -228,10 +236,12 @@ int main() {
   test_gemm(100, 32, 64, 4);
   test_gemm(100, 1, 64, 5);
   test_gemm(1, 384, 4096, 0);
+  test_gemm(200, 130, 128, 100); test_gemm(300, 200, 512, 101); test_gemm(1024, 64, 64, 100);
   test_conv(2, 16, 32, 48, 7, 0);
   test_conv(3, 32, 64, 32, 3, 2);
   test_conv(5, 48, 32, 70, 2, 3);
   test_conv(4, 96, 16, 1, 3, 5);
+  test_conv(5, 48, 32, 70, 2, 100); test_conv(3, 32, 64, 96, 3, 101); test_conv(9, 16, 32, 64, 7, 100);
   test_ln(5, 128); test_ln(40, 512); test_ln(16, 1024);
   test_gemm_lnfold(3, 48, 128, 0); test_gemm_lnfold(50, 96, 1024, 2); test_gemm_lnfold(200, 130, 512, 3);
   test_gemm_lnfold(130, 64, 1024, 7);
