@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=8)
     return ap.parse_args()
 
 
@@ -154,6 +154,17 @@ def kernel_profile(eng, job, nsteps=6):
     return rows, per_kernel, nsteps
 
 
+def pmc_traffic(name):
+    """HBM bytes per launch of `name` from the committed PMC passes (profiles/r01_pmc_traffic.json: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 calibration); None if that
+    kernel was not profiled.  PMC counters cannot be read from inside this process."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)["kernels"][name]["traffic_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def roofline_of(per_kernel):
     name, k = max(per_kernel.items(), key=lambda kv: kv[1]["total_ms"])
     avg_s = k["total_ms"] / k["count"] * 1e-3
@@ -161,9 +172,11 @@ def roofline_of(per_kernel):
     tfs = k["flops"] / k["count"] / avg_s / 1e12
     if tfs / MFMA_F32_PEAK_TF > gbs / HBM_PEAK_GBS:
         return dict(kernel=name, bound="mfma", achieved=tfs, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                    frac=tfs / MFMA_F32_PEAK_TF, traffic=None, avg_us=avg_s * 1e6, launches=k["count"])
+                    frac=tfs / MFMA_F32_PEAK_TF, traffic=pmc_traffic(name), avg_us=avg_s * 1e6, launches=k["count"],
+                    algorithmic_bytes_per_launch=k["bytes"] / k["count"], flops_per_launch=k["flops"] / k["count"])
     return dict(kernel=name, bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                traffic=None, avg_us=avg_s * 1e6, launches=k["count"])
+                traffic=pmc_traffic(name), avg_us=avg_s * 1e6, launches=k["count"],
+                algorithmic_bytes_per_launch=k["bytes"] / k["count"], flops_per_launch=k["flops"] / k["count"])
 
 
 def cpu_baseline(args, cfg, W, nsteps):
