@@ -100,6 +100,13 @@ int ptts_mimi_state_reset(ptts_mimi_state *s, void *stream);
  * emb_std/emb_mean de-normalisation, the quantizer 1x1 conv and increment_steps(mimi, 16). */
 int ptts_mimi_decode(ptts_engine *e, ptts_mimi_state *s, const float *d_latent, float *d_pcm, void *stream);
 
+/* ---- Voice-prompt encode path (one-off per voice): MimiModel.encode_to_latent + F.linear(speaker_proj_weight)
+ *      (mimi.py:96-119, tts_model.py:379-388).  d_audio f32[n_samples] mono at the model rate; the signal is
+ *      zero-padded to a whole number of frames.  Outputs (either may be NULL): d_latent_out f32[frames, ldim],
+ *      d_cond_out f32[frames, d_model] (feed it to ptts_lm_prefill after bos_before_voice).  Synchronises. */
+int ptts_encode_voice(ptts_engine *e, const float *d_audio, int64_t n_samples, float *d_latent_out,
+                      float *d_cond_out, int32_t *h_frames, void *stream);
+
 /* ---- hipGraph capture of one step (north star: "each decode step hipGraph-captured").
  * The captured step uses the same argument pointers on every launch. */
 int ptts_graph_capture_lm_step(ptts_engine *e, ptts_lm_state *s, const float *d_noise, int32_t lsd_steps,

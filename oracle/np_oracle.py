@@ -398,6 +398,85 @@ class MimiDecoder:
 
 
 # --------------------------------------------------------------------------
+# voice-prompt encode path (one-off per voice)
+# --------------------------------------------------------------------------
+def conv1d_strided(x, w, b, stride):
+    """`nn.Conv1d` with stride, no padding: w [O, C, K]."""
+    K = w.shape[2]
+    To = (x.shape[2] - K) // stride + 1
+    cols = np.stack([x[:, :, k : k + (To - 1) * stride + 1 : stride] for k in range(K)], axis=2)
+    y = np.einsum("ock,bckt->bot", w, cols, optimize=True)
+    if b is not None:
+        y = y + b[None, :, None]
+    return y.astype(F32)
+
+
+def causal_conv_full(x, w, b, stride=1, replicate=False):
+    """`StreamingConv1d.forward` with `model_state=None` on a whole signal: left context of
+    kernel - stride samples, zeros ("constant") or the first sample ("replicate")
+    (reference `conv.py:84-115`, `resample.py:18-26`)."""
+    TP = w.shape[2] - stride
+    if TP:
+        pad = np.repeat(x[..., :1], TP, axis=-1) if replicate else np.zeros(x.shape[:2] + (TP,), F32)
+        x = np.concatenate([pad, x], axis=-1)
+    return conv1d_strided(x, w, b, stride)
+
+
+def full_attention_layer_stack(h, W, prefix, num_layers, num_heads, context, max_period):
+    """`ProjectedTransformer` with `model_state=None`: whole sequence at once, RoPE offset 0, causal +
+    sliding-window mask (reference `transformer.py:63-75,135-158`, `mimi_transformer.py:140-150`)."""
+    B, T, C = h.shape
+    for i in range(num_layers):
+        st = dict(cache=np.full((2, B, T, num_heads, C // num_heads), np.nan, F32), offset=0)
+        h = transformer_layer(h, st, W, f"{prefix}.{i}", num_heads, context, max_period, None)
+    return h
+
+
+class VoiceEncoder:
+    """`MimiModel.encode_to_latent` + `TTSModel._encode_audio`
+    (reference `mimi.py:96-119`, `tts_model.py:379-388`)."""
+
+    def __init__(self, cfg, W):
+        from pocket_tts_amd.weights import seanet_encoder_layers  # inventory only
+
+        self.cfg, self.W = cfg, W
+        self.layers = seanet_encoder_layers(cfg)
+
+    def encode_to_latent(self, audio, taps=None):
+        """audio [B, 1, T] -> latent [B, inner_dim, ceil(T / frame_samples)]"""
+        W, cfg = self.W, self.cfg
+        fs = cfg.frame_samples
+        T = audio.shape[-1]
+        pad = (-T) % fs  # pad_for_conv1d(x, frame_size, frame_size): zeros at the end (conv.py:22-33)
+        x = np.concatenate([audio.astype(F32), np.zeros(audio.shape[:2] + (pad,), F32)], axis=-1)
+        for n, (idx, kind, cin, cout, k, stride) in enumerate(self.layers):
+            p = f"mimi.encoder.model.{idx}"
+            if kind == "res":
+                v = causal_conv_full(elu(x), W[p + ".block.1.conv.weight"], W[p + ".block.1.conv.bias"])
+                v = causal_conv_full(elu(v), W[p + ".block.3.conv.weight"], W[p + ".block.3.conv.bias"])
+                x = (x + v).astype(F32)
+            else:
+                if n > 0:
+                    x = elu(x)
+                x = causal_conv_full(x, W[p + ".conv.weight"], W[p + ".conv.bias"], stride)
+            if taps is not None:
+                taps[f"enc{idx}"] = x.copy()
+        tr = cfg.mimi.transformer
+        h = full_attention_layer_stack(x.transpose(0, 2, 1), W, "mimi.encoder_transformer.transformer.layers",
+                                       tr.num_layers, tr.num_heads, tr.context, float(tr.max_period))
+        x = h.transpose(0, 2, 1).astype(F32)
+        if taps is not None:
+            taps["enc_tr"] = x.copy()
+        # ConvDownsample1d: kernel 2*stride, stride, replicate padding, no bias (resample.py:7-29)
+        return causal_conv_full(x, W["mimi.downsample.conv.conv.weight"], None, cfg.upsample_stride, replicate=True)
+
+    def conditioning(self, audio):
+        """-> [B, frames, d_model] = latents^T @ speaker_proj_weight^T (tts_model.py:386-388)"""
+        lat = self.encode_to_latent(audio)
+        return linear(lat.transpose(0, 2, 1), self.W["flow_lm.speaker_proj_weight"])
+
+
+# --------------------------------------------------------------------------
 # the two hot loops (reference `tts_model.py:744-779` and `:433-474`)
 # --------------------------------------------------------------------------
 def autoregressive_generation(lm, state, max_gen_len, frames_after_eos, noise=None,

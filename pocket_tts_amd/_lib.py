@@ -57,6 +57,7 @@ PROTOTYPES = {
     "ptts_mimi_state_destroy": (None, [_P]),
     "ptts_mimi_state_reset": (C.c_int, [_P, _P]),
     "ptts_mimi_decode": (C.c_int, [_P, _P, _P, _P, _P]),
+    "ptts_encode_voice": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.POINTER(C.c_int32), _P]),
     "ptts_graph_capture_lm_step": (C.c_int, [_P, _P, _P, C.c_int32, C.c_float, _P, _P, _P, C.POINTER(_P)]),
     "ptts_graph_capture_mimi": (C.c_int, [_P, _P, _P, _P, C.POINTER(_P)]),
     "ptts_graph_capture_pipelined": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_float, _P, _P, _P, _P, _P, C.POINTER(_P)]),

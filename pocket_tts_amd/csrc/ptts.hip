@@ -93,6 +93,11 @@ struct ptts_engine {
   std::vector<TrLayer> mm;
   Lin conv0, convtr[3], res_a[3], res_b[3], conv_last;
   int ring = 0;
+  // voice-prompt encode path (SEANet encoder, encoder transformer, downsample, speaker projection)
+  bool has_encoder = false;
+  Lin enc_conv0, enc_res_a[3], enc_res_b[3], enc_down[3], enc_final, enc_downsample, speaker_proj;
+  std::vector<TrLayer> enc_tr;
+  float *zeros = nullptr;
   int64_t lm_bytes = 0, mimi_bytes = 0;
 };
 
@@ -195,7 +200,8 @@ struct PackPart { std::string w, b; int N; };
 
 // packs one or several [N_i][C][ntaps] matrices (stacked along N) into one Lin
 static int pack_lin(ptts_engine *e, Lin *L, const std::vector<PackPart> &parts, int C, int ntaps, int mode = 0,
-                    int cout = 0, int stride = 0, const std::string &ln_w = "", const std::string &ln_b = "") {
+                    int cout = 0, int stride = 0, const std::string &ln_w = "", const std::string &ln_b = "",
+                    int creal = 0) {
   if (C % 16) return fail(-4, "channel count must be a multiple of 16: " + parts[0].w);
   int ntot = 0;
   for (auto &p : parts) ntot += cdiv(p.N, 16);
@@ -226,12 +232,12 @@ static int pack_lin(ptts_engine *e, Lin *L, const std::vector<PackPart> &parts, 
   int nt_off = 0;
   for (auto &p : parts) {
     int err = 0;
-    const ptts_tensor *t = find_tensor(e, p.w, (int64_t)(mode == 0 ? p.N : (p.N / stride)) * C * (mode == 0 ? ntaps : 2 * stride), &err);
+    const ptts_tensor *t = find_tensor(e, p.w, (int64_t)(mode == 0 ? p.N : (p.N / stride)) * (creal > 0 ? creal : C) * (mode == 0 ? ntaps : 2 * stride), &err);
     if (!t) return err;
     int nt = cdiv(p.N, 16);
     long total = (long)nt * L->KF * 256;
     pack_weight_kernel<<<cdiv(total, 256), 256, 0, e->stream>>>(t->d_data, L->w, p.N, C, ntaps, mode, cout, stride,
-                                                                nt_off, L->KF, total, gam);
+                                                                nt_off, L->KF, total, gam, creal > 0 ? creal : C);
     if (gam) {
       const float *bsrc = nullptr;
       if (!p.b.empty()) {
@@ -330,7 +336,11 @@ static const char *const kCfgName[10] = {"gemm<1,1,8,1,1>", "gemm<1,2,4,1,1>", "
                                         "gemm<2,4,1,1,4>", "gemm<1,4,1,1,4>", "gemm<1,1,1,1,4>", "gemm<2,4,4,1,1>",
                                          "gemm_lds<4,8,2>", "gemm_lds<4,4,2>"};
 
-static void launch_gemm(hipStream_t st, const GemmArgs &a, int pre) {
+static thread_local const float *g_zeros = nullptr;  // set by the entry points from the engine
+
+static void launch_gemm(hipStream_t st, const GemmArgs &a_in, int pre) {
+  GemmArgs a = a_in;
+  a.zeros = g_zeros;
   // algorithmic traffic: weights once + input rows once (x taps re-read from cache, not counted) + output
   const double K = (double)a.KF * 16, N = (double)a.NT * 16, M = (double)a.M;
   double bytes = 4.0 * (N * K + M * (double)a.CF * 16 + M * N);
@@ -369,6 +379,9 @@ static GemmArgs mk_gemm(const Lin &L, const float *X, int XF, int MT, int M) {
   a.MT = MT;
   a.M = M;
   a.T = 16;
+  a.xstride = 1;
+  a.halo = L.ntaps - 1;  // streaming causal conv: kernel - 1 rows of left context (stride 1)
+  a.halo_mode = 0;
   a.epi = EPI_STORE;
   a.act = ACT_NONE;
   return a;
@@ -551,6 +564,33 @@ extern "C" int ptts_create(const ptts_config *cfg, const ptts_tensor *tensors, i
     std::string m = "mimi.decoder.model." + std::to_string(idx + 1);
     CHK(pack_lin(e, &e->conv_last, {{m + ".conv.weight", m + ".conv.bias", 1}}, nf, c.last_kernel_size));
   }
+  CHK(dallocT(e, &e->zeros, 64));
+  if (e->tmap.count("mimi.encoder.model.0.conv.weight") && e->tmap.count("flow_lm.speaker_proj_weight")) {
+    // reference mimi.py:96-119, seanet.py:63-104, resample.py:7-29, tts_model.py:379-388
+    int em = 1, eidx = 1;
+    CHK(pack_lin(e, &e->enc_conv0, {{"mimi.encoder.model.0.conv.weight", "mimi.encoder.model.0.conv.bias", nf}}, 16,
+                 c.kernel_size, 0, 0, 0, "", "", 1));  // mono input padded to 16 channels
+    for (int i = 0; i < 3; ++i) {
+      const int dim = em * nf, r = c.ratios[2 - i], hid = dim / c.compress;
+      std::string rb = "mimi.encoder.model." + std::to_string(eidx);
+      CHK(pack_lin(e, &e->enc_res_a[i], {{rb + ".block.1.conv.weight", rb + ".block.1.conv.bias", hid}}, dim, c.res_kernel_size));
+      CHK(pack_lin(e, &e->enc_res_b[i], {{rb + ".block.3.conv.weight", rb + ".block.3.conv.bias", dim}}, hid, 1));
+      std::string dn = "mimi.encoder.model." + std::to_string(eidx + 2);
+      CHK(pack_lin(e, &e->enc_down[i], {{dn + ".conv.weight", dn + ".conv.bias", 2 * dim}}, dim, 2 * r));
+      e->enc_down[i].stride = r;
+      eidx += 3;
+      em *= 2;
+    }
+    std::string fn = "mimi.encoder.model." + std::to_string(eidx + 1);
+    CHK(pack_lin(e, &e->enc_final, {{fn + ".conv.weight", fn + ".conv.bias", C}}, em * nf, c.last_kernel_size));
+    e->enc_tr.resize(c.m_layers);
+    for (int l = 0; l < c.m_layers; ++l)
+      CHK(pack_tr_layer(e, &e->enc_tr[l], "mimi.encoder_transformer.transformer.layers." + std::to_string(l), C, c.m_ff, true));
+    CHK(pack_lin(e, &e->enc_downsample, {{"mimi.downsample.conv.conv.weight", "", c.ldim}}, C, 2 * c.upsample_stride));
+    e->enc_downsample.stride = c.upsample_stride;
+    CHK(pack_lin(e, &e->speaker_proj, {{"flow_lm.speaker_proj_weight", "", D}}, c.ldim, 1));
+    e->has_encoder = true;
+  }
   e->mimi_bytes = e->quant.bytes() + e->conv0.bytes() + e->conv_last.bytes();
   for (auto &L : e->mm) e->mimi_bytes += L.qkv.bytes() + L.out.bytes() + L.ff1.bytes() + L.ff2.bytes();
   for (int i = 0; i < 3; ++i) e->mimi_bytes += e->convtr[i].bytes() + e->res_a[i].bytes() + e->res_b[i].bytes();
@@ -576,6 +616,7 @@ static hipStream_t S(ptts_engine *e, void *stream) { return stream ? (hipStream_
 // time-embedding constant for a given LSD schedule (reference mlp.py:203-206): computed once on device
 static int prepare_lsd(ptts_engine *e, int steps) {
   if (e->tcomb.count(steps)) return 0;
+  g_zeros = e->zeros;
   if (steps < 1 || steps > 64) return fail(-1, "lsd_decode_steps out of range");
   const int FD = e->cfg.flow_dim;
   float *tab;
@@ -800,6 +841,7 @@ extern "C" int64_t ptts_profile_stop(ptts_engine *e, char *h_out, int64_t capaci
 
 static void lm_layers(hipStream_t st, ptts_engine *e, ptts_lm_state *s, Scratch &sc, int M, int Tq) {
   const ptts_config &c = e->cfg;
+  g_zeros = e->zeros;
   SITE("lm.rope");
   {
     ProfScope ps(st, "rope_table", 256.0 * M, 0);
@@ -850,6 +892,7 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
                            const float *d_noise, int lsd_steps, float eos_thr, float *d_latent_out,
                            float *d_eos_logit, uint8_t *d_is_eos) {
   const ptts_config &c = e->cfg;
+  g_zeros = e->zeros;
   const int B = s->B, MT = s->MT, D = c.d_model, FD = c.flow_dim, DF = D / 16, FDF = FD / 16, LF = c.ldim / 16;
   Scratch &sc = s->dec;
   const float *tcomb = e->tcomb[lsd_steps];
@@ -1016,6 +1059,7 @@ extern "C" int ptts_mimi_state_reset(ptts_mimi_state *s, void *stream) {
 
 static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, const float *d_latent, float *d_pcm) {
   const ptts_config &c = e->cfg;
+  g_zeros = e->zeros;
   const int B = s->B, C = c.m_dim, CF = C / 16, LF = c.ldim / 16, st16 = c.upsample_stride;
   SITE("mimi.prep");
   {
@@ -1112,6 +1156,123 @@ extern "C" int ptts_mimi_decode(ptts_engine *e, ptts_mimi_state *s, const float 
   CHK(mimi_enqueue(S(e, stream), e, s, d_latent, d_pcm));
   s->h_frame += 1;
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Voice-prompt encode path (one-off per voice): MimiModel.encode_to_latent + speaker projection
+// (reference mimi.py:96-119, tts_model.py:379-388).  Whole-signal causal convs = the same implicit GEMMs with
+// zero / replicate left padding and an input stride.
+extern "C" int ptts_encode_voice(ptts_engine *e, const float *d_audio, int64_t n_samples, float *d_latent_out,
+                                 float *d_cond_out, int32_t *h_frames, void *stream) {
+  if (!e->has_encoder) return fail(-3, "the checkpoint passed to ptts_create has no Mimi encoder tensors");
+  if (n_samples < 1) return fail(-1, "empty audio");
+  HIPCHK(hipSetDevice(e->device));
+  const ptts_config &c = e->cfg;
+  hipStream_t st = S(e, stream);
+  g_zeros = e->zeros;
+  g_alloc_stream = st;
+  const int hop = c.ratios[0] * c.ratios[1] * c.ratios[2];
+  const long fs = (long)hop * c.upsample_stride;  // 1920
+  const long R0 = (n_samples + fs - 1) / fs * fs;  // pad_for_conv1d(x, frame_size, frame_size)
+  const int Tf = (int)(R0 / fs);
+  const int C = c.m_dim, nf = c.n_filters;
+  std::vector<void *> tmp;
+  auto talloc = [&](float **p, size_t n) { int r = dallocT(nullptr, p, n); if (r == 0) tmp.push_back(*p); return r; };
+  float *x0, *cur_r, *cur_e;
+  CHK(talloc(&x0, (size_t)R0 * 16));
+  CHK(talloc(&cur_r, (size_t)R0 * nf));
+  CHK(talloc(&cur_e, (size_t)R0 * nf));
+  audio_to_fm_kernel<<<cdiv(R0 / 16 * 64, 256), 256, 0, st>>>(d_audio, x0, (int)n_samples, (int)R0);
+  long rows = R0;
+  auto conv = [&](const Lin &L, const float *X, int XF, long out_rows, int xstride, int halo, int mode) {
+    GemmArgs a = mk_gemm(L, X, XF, (int)cdiv(out_rows, 16), (int)out_rows);
+    a.T = cdiv(out_rows, 16) * 16;  // one sequence: t == row
+    a.xstride = xstride; a.halo = halo; a.halo_mode = mode;
+    return a;
+  };
+  SITE("enc.conv0");
+  GemmArgs a = conv(e->enc_conv0, x0, 1, rows, 1, c.kernel_size - 1, 1);
+  a.Y = cur_e; a.YF = nf / 16; a.act = ACT_ELU; a.Yraw = cur_r;
+  launch_gemm(st, a, PRE_NONE);
+  int dim = nf;
+  for (int i = 0; i < 3; ++i) {
+    const int r = c.ratios[2 - i], hid = dim / c.compress;
+    float *rb, *se, *nr, *ne;
+    CHK(talloc(&rb, (size_t)rows * hid));
+    CHK(talloc(&se, (size_t)rows * dim));
+    SITE("enc.res_a");
+    a = conv(e->enc_res_a[i], cur_e, dim / 16, rows, 1, c.res_kernel_size - 1, 1);
+    a.Y = rb; a.YF = hid / 16; a.act = ACT_ELU;
+    launch_gemm(st, a, PRE_NONE);
+    SITE("enc.res_b");
+    a = conv(e->enc_res_b[i], rb, hid / 16, rows, 1, 0, 1);
+    a.epi = EPI_RES; a.R = cur_r; a.RF = dim / 16; a.Y = se; a.YF = dim / 16; a.act = ACT_ELU;
+    launch_gemm(st, a, PRE_NONE);
+    const long nrows = rows / r;
+    CHK(talloc(&nr, (size_t)nrows * 2 * dim));
+    CHK(talloc(&ne, (size_t)nrows * 2 * dim));
+    SITE("enc.down");
+    a = conv(e->enc_down[i], se, dim / 16, nrows, r, r, 1);  // kernel 2r, stride r: left context r
+    a.Y = ne; a.YF = 2 * dim / 16; a.act = ACT_ELU; a.Yraw = nr;
+    launch_gemm(st, a, PRE_NONE);
+    cur_r = nr; cur_e = ne; rows = nrows; dim *= 2;
+  }
+  // final conv -> encoder-transformer input (rows = R0 / hop, a multiple of 16)
+  const int M2 = (int)rows, MT2 = M2 / 16;
+  const long ds_rows_in = (long)cdiv(Tf, 16) * 16 * c.upsample_stride;  // rows the downsample may touch
+  float *tx;
+  CHK(talloc(&tx, (size_t)std::max<long>(M2, ds_rows_in) * C));
+  SITE("enc.final");
+  a = conv(e->enc_final, cur_e, dim / 16, M2, 1, c.last_kernel_size - 1, 1);
+  a.Y = tx; a.YF = C / 16;
+  launch_gemm(st, a, PRE_NONE);
+  // encoder transformer, whole sequence, RoPE offset 0, window = context (transformer.py:63-75)
+  {
+    const int H = c.m_heads, QB = MT2, cap = MT2 * 16;
+    float *ao, *ff, *q, *part, *rope, *kv;
+    int *off;
+    const int splits = attn_splits(H * QB, std::min(MT2, cdiv(c.m_context, 16) + 2));
+    CHK(talloc(&ao, (size_t)M2 * C));
+    CHK(talloc(&ff, (size_t)M2 * c.m_ff));
+    CHK(talloc(&q, (size_t)H * QB * 4 * 256));
+    CHK(talloc(&part, (size_t)H * QB * splits * 16 * ATT_PSTRIDE));
+    CHK(talloc(&rope, (size_t)M2 * 64));
+    CHK(talloc(&kv, (size_t)2 * H * cap * 64));
+    CHK(talloc((float **)&off, 4));
+    rope_table_kernel<<<cdiv(M2 * 32, 256), 256, 0, st>>>(off, e->freq_mimi, rope, M2, M2);
+    for (int l = 0; l < c.m_layers; ++l) {
+      TrCtx t;
+      t.D = C; t.H = H; t.FF = c.m_ff; t.MT = MT2; t.M = M2; t.Tq = M2; t.QB = QB;
+      t.cap = cap; t.ring = 0; t.ctx = c.m_context; t.splits = splits;
+      t.x_in = tx; t.x = tx; t.x_out = tx; t.out_ds = 0; t.par = nullptr;
+      t.h = nullptr; t.ao = ao; t.ff = ff; t.q = q; t.part = part;
+      t.Kc = kv; t.Vc = kv + (size_t)H * cap * 64; t.offset = off; t.rope = rope;
+      t.kv_keys = (double)M2 * std::min(M2, c.m_context) / 16.0;
+      t.tag = "enc";
+      run_tr_layer(st, e->enc_tr[l], t);
+    }
+  }
+  // ConvDownsample1d: kernel 2s, stride s, replicate padding, no bias (resample.py:7-29)
+  float *lat, *cond;
+  const int MT3 = cdiv(Tf, 16);
+  CHK(talloc(&lat, (size_t)MT3 * 16 * c.ldim));
+  CHK(talloc(&cond, (size_t)MT3 * 16 * c.d_model));
+  SITE("enc.downsample");
+  a = conv(e->enc_downsample, tx, C / 16, Tf, c.upsample_stride, c.upsample_stride, 2);
+  a.Y = lat; a.YF = c.ldim / 16;
+  launch_gemm(st, a, PRE_NONE);
+  SITE("enc.speaker_proj");
+  a = mk_gemm(e->speaker_proj, lat, c.ldim / 16, MT3, Tf);
+  a.Y = cond; a.YF = c.d_model / 16;
+  launch_gemm(st, a, PRE_NONE);
+  SITE("");
+  if (d_latent_out) from_fm_kernel<<<cdiv((long)Tf * c.ldim / 4, 256), 256, 0, st>>>(lat, d_latent_out, Tf, c.ldim, c.ldim / 16, 0);
+  if (d_cond_out) from_fm_kernel<<<cdiv((long)Tf * c.d_model / 4, 256), 256, 0, st>>>(cond, d_cond_out, Tf, c.d_model, c.d_model / 16, 0);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  for (void *p : tmp) hipFree(p);
+  if (h_frames) *h_frames = Tf;
   return 0;
 }
 

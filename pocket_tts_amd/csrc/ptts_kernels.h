@@ -59,6 +59,11 @@ struct GemmArgs {
   const float *X;
   long Xdstride;
   int XF, MT, M, T;  // M = valid rows, T = rows per sequence (multiple of 16 when ntaps > 1)
+  // conv addressing: input row of (output row t, tap) = t * xstride + tap - halo.  Rows before the start
+  // of the sequence come from the previous-frame buffer (halo_mode 0, streaming decode), are zero (1,
+  // whole-signal "constant" padding) or repeat the first row (2, "replicate"): reference conv.py:84-115
+  int xstride, halo, halo_mode;
+  const float *zeros;  // >= 16 B of zeros (halo_mode 1)
   const int *par;    // device frame counter (parity = *par & 1) or null
   const float *prevec;  // PRE_ADDSILU: per-k vector
   // PRE_LNFOLD: LayerNorm folded into this GEMM.  W is packed with the LN gain multiplied in (W' = W diag(g)),
@@ -120,6 +125,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 acc, int 
   }
   switch (a.epi) {
     case EPI_STORE: {
+      if (a.Yraw) *(f32x4 *)(a.Yraw + par * a.Yrawdstride + (((size_t)mt * a.YF + nt) * 64 + lane) * 4) = acc;
       acc = act4(acc, a.act);
       float *y = a.Y + par * a.Ydstride;
       *(f32x4 *)(y + (((size_t)mt * a.YF + nt) * 64 + lane) * 4) = acc;
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
     tap = k0 / a.CF;
     cf = k0 - tap * a.CF;
   }
-  const int halo = a.ntaps - 1;
+  const int halo = a.halo;
   // Software pipeline over chunks of U k-fragments: the 1 KiB operand loads of chunk c+1 are issued before the
   // MFMAs of chunk c, into a second register set, so the matrix pipe works while the next operands fly.
   constexpr int U = (TN * TM == 1) ? 8 : (TN * TM <= 4 && WK > 1) ? 4 : 2;
@@ -277,10 +283,16 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
       } else {
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-          int ts = tin[j] + tap - halo;
-          const float *src = ts >= 0 ? Xc : Xp;
-          int rr = bT[j] + (ts >= 0 ? ts : a.T + ts);
-          x[u][j] = *(const f32x4 *)(src + (((size_t)(rr >> 4) * a.XF + cf) * 64 + (lane & 48) + (rr & 15)) * 4);
+          const int ts = tin[j] * a.xstride + tap - halo;
+          const float *src = Xc;
+          long rr = (long)bT[j] * a.xstride + ts;
+          if (ts < 0) {
+            if (a.halo_mode == 0) { src = Xp; rr += (long)a.T * a.xstride; }
+            else if (a.halo_mode == 2) rr = (long)bT[j] * a.xstride;
+          }
+          const float *ptr = src + (((size_t)(rr >> 4) * a.XF + cf) * 64 + (lane & 48) + (rr & 15)) * 4;
+          if (ts < 0 && a.halo_mode == 1) ptr = a.zeros;
+          x[u][j] = *(const f32x4 *)ptr;
         }
         if (++cf == a.CF) { cf = 0; ++tap; }
       }
@@ -460,7 +472,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
   const int par = a.par ? (*a.par & 1) : 0;
   const float *Xc = a.X + par * a.Xdstride;
   const float *Xp = a.X + (par ^ 1) * a.Xdstride;
-  const int halo = a.ntaps - 1;
+  const int halo = a.halo;
 
   // loader bookkeeping: this wave copies X fragments of m-tiles {wave, wave+4, ..} and W fragments f % 4 == wave
   int l_mt[XPW], l_t[XPW], l_bT[XPW];
@@ -487,10 +499,15 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
         if (a.ntaps == 1) {
           src = Xc + (((size_t)l_mt[q] * a.XF + kf) * 64 + lane) * 4;
         } else {
-          int ts = l_t[q] + tap - halo;
-          const float *base = ts >= 0 ? Xc : Xp;
-          int rr = l_bT[q] + (ts >= 0 ? ts : a.T + ts);
+          const int ts = l_t[q] * a.xstride + tap - halo;
+          const float *base = Xc;
+          long rr = (long)l_bT[q] * a.xstride + ts;
+          if (ts < 0) {
+            if (a.halo_mode == 0) { base = Xp; rr += (long)a.T * a.xstride; }
+            else if (a.halo_mode == 2) rr = (long)l_bT[q] * a.xstride;
+          }
           src = base + (((size_t)(rr >> 4) * a.XF + cf) * 64 + (lane & 48) + (rr & 15)) * 4;
+          if (ts < 0 && a.halo_mode == 1) src = a.zeros;
         }
         GLDS16(src, &lds[buf][kc * BMT + wave + 4 * q][0]);
       }
@@ -579,7 +596,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
 // dst[nt][tap*CF + cf][lane][j4] = W[n = 16nt + (lane&15)][c = 16cf + 4(lane>>4) + j4][tap]
 // ---------------------------------------------------------------------------------------------
 __global__ void pack_weight_kernel(const float *src, float *dst, int N, int C, int ntaps, int mode, int cout,
-                                   int stride, int nt_off, int KF, long total, const float *colscale) {
+                                   int stride, int nt_off, int KF, long total, const float *colscale, int Creal) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   int j4 = i & 3;
@@ -594,7 +611,7 @@ __global__ void pack_weight_kernel(const float *src, float *dst, int N, int C, i
   float v = 0.f;
   if (n < N) {
     if (mode == 0) {
-      v = src[((size_t)n * C + c) * ntaps + tap];
+      v = c < Creal ? src[((size_t)n * Creal + c) * ntaps + tap] : 0.f;
       if (colscale) v *= colscale[c];
     } else {
       int j = n / cout, nn = n - j * cout;
@@ -765,6 +782,17 @@ __global__ void rope_table_kernel(const int *offset, const float *freq, float *t
   sincosf(freq[f] * (float)(offset[b] + t), &sn, &cs);
   tab[2 * i] = cs;
   tab[2 * i + 1] = sn;
+}
+
+// mono audio [T] -> FM rows of 16 channels (channel 0 = sample, the rest zero) for the encoder's first conv
+__global__ void audio_to_fm_kernel(const float *audio, float *x_fm, int n_valid, int n_rows) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;  // one float4 slot per (row tile, lane)
+  if (i >= (n_rows / 16) * 64) return;
+  int lane = i & 63, mt = i >> 6;
+  int m = 16 * mt + (lane & 15);
+  f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if ((lane >> 4) == 0 && m < n_valid) v.x = audio[m];
+  *(f32x4 *)(x_fm + (size_t)i * 4) = v;
 }
 
 __global__ void add_int_kernel(int *p, int n, int inc) {

@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 from .config import Config
-from .weights import state_dict_spec
+from .weights import mimi_encode_spec, state_dict_spec
 
 
 def _ptr(t: torch.Tensor | None):
@@ -135,6 +135,10 @@ class Engine:
             raise RuntimeError("pocket_tts_amd runs on a ROCm GPU only (device must be cuda:N)")
         torch.cuda.set_device(self.device)
         spec = state_dict_spec(cfg)
+        optional = set(mimi_encode_spec(cfg))  # checkpoints without voice cloning may lack the encoder
+        if any(n not in weights for n in optional):
+            spec = {k: v for k, v in spec.items() if k not in optional}
+        self.has_voice_encoder = all(n in weights for n in optional)
         keep, arr = [], (_lib.PttsTensor * len(spec))()
         for i, (name, shape) in enumerate(spec.items()):
             if name not in weights:
@@ -286,6 +290,21 @@ class Engine:
 
     def graph_destroy(self, g):
         self.lib.ptts_graph_destroy(g)
+
+    # ---- voice-prompt encode path
+    def encode_voice(self, audio: torch.Tensor):
+        """audio f32[n_samples] (mono, model sample rate) -> (latent [frames, ldim], conditioning [frames, D]):
+        `MimiModel.encode_to_latent` + speaker projection (reference mimi.py:96-119, tts_model.py:379-388)."""
+        audio = audio.reshape(-1).to(self.device, torch.float32).contiguous()
+        n = audio.numel()
+        frames = -(-n // self.frame_samples)
+        lat = torch.empty((frames, self.ldim), dtype=torch.float32, device=self.device)
+        cond = torch.empty((frames, self.D), dtype=torch.float32, device=self.device)
+        self._pre()
+        nf = C.c_int32()
+        _lib.check(self.lib.ptts_encode_voice(self.handle, _ptr(audio), n, _ptr(lat), _ptr(cond), C.byref(nf), self._sp))
+        assert nf.value == frames
+        return lat, cond
 
     # ---- Mimi
     def mimi_decode(self, state: MimiState, latent: torch.Tensor, out_pcm=None) -> torch.Tensor:

@@ -86,7 +86,7 @@ class TTSModel:
         self.noise_clamp = noise_clamp
         self.eos_threshold = eos_threshold
         self.origin = origin
-        self.has_voice_cloning = False  # the Mimi encoder path is not part of this build yet
+        self.has_voice_cloning = engine.has_voice_encoder
         self._ctx_cache: dict = {}
         self.pad_with_spaces_for_short_inputs = config.pad_with_spaces_for_short_inputs
         self.model_recommended_frames_after_eos = config.model_recommended_frames_after_eos
@@ -133,9 +133,9 @@ class TTSModel:
 
     # ---- voice state ------------------------------------------------------------------------
     def get_state_for_audio_prompt(self, audio_conditioning, truncate: bool = False) -> dict:
-        """`.safetensors` voice states load exactly as in the reference (tts_model.py:846-851,1055-1072).
-        Encoding a waveform needs the Mimi encoder, which this build does not
-        contain yet; pre-computed conditioning can be passed to `get_state_for_conditioning`."""
+        """Voice state from a `.safetensors` file (tts_model.py:846-851,1055-1072), a WAV file or an audio
+        tensor [1, samples] at the model sample rate (tts_model.py:874-899): the waveform goes through the
+        Mimi encoder + speaker projection on the GPU (`Engine.encode_voice`) and is prefilled."""
         if isinstance(audio_conditioning, (str, Path)) and str(audio_conditioning).endswith(".safetensors"):
             if str(audio_conditioning).startswith(("hf://", "http://", "https://")):
                 raise FileNotFoundError(f"{audio_conditioning} needs a download; this build runs offline")
@@ -146,11 +146,17 @@ class TTSModel:
                                  f"associated with a language.Here the origin is {self.origin}")
             raise FileNotFoundError(f"predefined voice '{audio_conditioning}' needs a download; this build runs "
                                     "offline: pass a local .safetensors voice state instead")
-        raise ValueError(
-            "We could not load the model with voice cloning: encoding an audio prompt needs the Mimi encoder, "
-            "which is not part of the MI355X hot-path build yet. Use a .safetensors voice state exported by the "
-            "reference (export_model_state) or get_state_for_conditioning()."
-        )
+        if not self.has_voice_cloning:
+            raise ValueError("We could not load the weights for the model with voice cloning, but you're trying to "
+                             "use voice cloning: the checkpoint has no Mimi encoder tensors.")
+        if isinstance(audio_conditioning, (str, Path)):
+            audio, sr = _audio_read(audio_conditioning)
+            if truncate:
+                audio = audio[..., : int(30 * sr)]  # first 30 seconds (tts_model.py:880-884)
+            audio_conditioning = _convert_audio(audio, sr, self.config.mimi.sample_rate)
+        # audio tensor [channels=1, samples] at the model rate -> conditioning (tts_model.py:889-890,379-388)
+        _, cond = self.engine.encode_voice(audio_conditioning)
+        return self.get_state_for_conditioning(cond[None])
 
     def get_state_for_conditioning(self, conditioning: torch.Tensor) -> dict:
         """Voice state from pre-computed speaker conditioning f32[1, T, d_model] (the output of the
@@ -273,6 +279,31 @@ class TTSModel:
         dur_ms = int(total * 1000 / self.config.mimi.sample_rate)
         gen_ms = max(1, int((time.monotonic() - t_start) * 1000))
         logger.info("Generated: %d ms of audio in %d ms so %.2fx faster than real-time", dur_ms, gen_ms, dur_ms / gen_ms)
+
+
+def _audio_read(path):
+    """WAV via the standard library (reference data/audio.py:23-36): int16 -> float32 / 32768, channel mean."""
+    import wave
+
+    path = Path(path)
+    if path.suffix.lower() != ".wav":
+        raise ImportError("only WAV files are supported for audio prompts in this build")
+    with wave.open(str(path), "rb") as w:
+        sr, nch = w.getframerate(), w.getnchannels()
+        x = np.frombuffer(w.readframes(-1), dtype=np.int16).astype(np.float32) / 32768.0
+    if nch > 1:
+        x = x.reshape(-1, nch).mean(axis=1)
+    return torch.from_numpy(x).unsqueeze(0), sr
+
+
+def _convert_audio(wav: torch.Tensor, from_rate: int, to_rate: int) -> torch.Tensor:
+    """polyphase resampling like the reference (data/audio_utils.py:8-28)"""
+    if from_rate != to_rate:
+        from scipy.signal import resample_poly
+
+        g = math.gcd(int(from_rate), int(to_rate))
+        wav = torch.from_numpy(resample_poly(wav.cpu().numpy(), int(to_rate) // g, int(from_rate) // g, axis=-1)).to(wav.dtype)
+    return wav
 
 
 # ---- model-state helpers (reference format) ---------------------------------------------------

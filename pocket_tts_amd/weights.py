@@ -172,9 +172,53 @@ def mimi_decode_spec(cfg: Config) -> dict:
     return s
 
 
+def seanet_encoder_layers(cfg: Config) -> list:
+    """Structure of `SEANetEncoder.model` (reference `seanet.py:63-104`): list of
+    (index-in-ModuleList, kind, cin, cout, kernel, stride) with kind in conv / res / down."""
+    sn = cfg.mimi.seanet
+    assert sn.n_residual_layers == 1
+    mult = 1
+    layers = [(0, "conv", sn.channels, mult * sn.n_filters, sn.kernel_size, 1)]
+    idx = 1
+    for r in reversed(sn.ratios):
+        dim = mult * sn.n_filters
+        layers.append((idx, "res", dim, dim // sn.compress, sn.residual_kernel_size, 1))
+        layers.append((idx + 2, "down", dim, 2 * dim, 2 * r, r))  # idx + 1 = ELU
+        idx += 3
+        mult *= 2
+    layers.append((idx + 1, "conv", mult * sn.n_filters, sn.dimension, sn.last_kernel_size, 1))
+    return layers
+
+
+def mimi_encode_spec(cfg: Config) -> dict:
+    """Encode-side tensors of `mimi.*` used by the voice-prompt path (reference `mimi.py:96-119`)."""
+    m = cfg.mimi
+    s: dict = {}
+    for idx, kind, cin, cout, k, stride in seanet_encoder_layers(cfg):
+        p = f"mimi.encoder.model.{idx}"
+        if kind == "res":
+            hid = cout
+            s[f"{p}.block.1.conv.weight"] = (hid, cin, k)
+            s[f"{p}.block.1.conv.bias"] = (hid,)
+            s[f"{p}.block.3.conv.weight"] = (cin, hid, 1)
+            s[f"{p}.block.3.conv.bias"] = (cin,)
+        else:
+            s[f"{p}.conv.weight"] = (cout, cin, k)
+            s[f"{p}.conv.bias"] = (cout,)
+    tr = m.transformer
+    for i in range(tr.num_layers):
+        s.update(_transformer_layer(f"mimi.encoder_transformer.transformer.layers.{i}", tr.d_model,
+                                    tr.dim_feedforward, True))
+    st = cfg.upsample_stride
+    inner = m.inner_dim or m.seanet.dimension
+    s["mimi.downsample.conv.conv.weight"] = (inner, m.seanet.dimension, 2 * st)
+    return s
+
+
 def state_dict_spec(cfg: Config) -> dict:
     s = flow_lm_spec(cfg)
     s.update(mimi_decode_spec(cfg))
+    s.update(mimi_encode_spec(cfg))
     return s
 
 

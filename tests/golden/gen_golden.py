@@ -222,6 +222,38 @@ def gen_case(name: str, cfg: Config, mods, seed: int, B: int, Tv: int, Tt: int, 
     return out
 
 
+@torch.no_grad()
+def gen_encode_case(cname: str, mods, seed: int, n_samples: int, B: int = 1):
+    """`MimiModel.encode_to_latent` on seeded noise + the speaker projection (tts_model.py:379-388)."""
+    cfg = named_config(cname)
+    lm, mimi, W = build_reference(cfg, mods, seed)
+    g = torch.Generator().manual_seed(seed + 31)
+    audio = torch.randn(B, 1, n_samples, generator=g) * 0.2
+    out = {"audio": audio.numpy()}
+    rec = {}
+    hooks = []
+    for idx, layer in enumerate(mimi.encoder.model):
+        if not isinstance(layer, torch.nn.ELU):
+            hooks.append(layer.register_forward_hook(
+                lambda _m, _i, o, k=f"enc{idx}": rec.__setitem__(k, o.numpy().copy())))
+    hooks.append(mimi.encoder_transformer.register_forward_hook(
+        lambda _m, _i, o: rec.__setitem__("enc_tr", o[0].numpy().copy())))
+    lat = mimi.encode_to_latent(audio)
+    for h in hooks:
+        h.remove()
+    out["latent"] = lat.numpy().copy()
+    spw = torch.from_numpy(generate_tensor("flow_lm.speaker_proj_weight",
+                                           (cfg.flow_lm.transformer.d_model, cfg.mimi.inner_dim), seed))
+    out["conditioning"] = torch.nn.functional.linear(lat.transpose(-1, -2).to(torch.float32), spw).numpy().copy()
+    if cname == "tiny":  # per-layer taps only for the small config (fixture size)
+        for k, v in rec.items():
+            out["tap_" + k] = v
+    out["meta"] = np.array(repr(dict(config=cname, seed=seed, n_samples=n_samples, B=B)))
+    return out
+
+
+ENCODE_CASES = {"encode_tiny": ("tiny", 2 * 1920 + 700), "encode_en100m": ("en100m", 3 * 1920)}
+
 CASES = {
     # name: (config, B, Tv, Tt, n_steps, n_frames, lsd_steps, with_noise, taps)
     "tiny_b2": ("tiny", 2, 5, 3, 12, 6, 1, False, True),
@@ -240,6 +272,13 @@ def main():
     torch.set_num_threads(8)
     mods = import_reference_modules()
     outdir = Path(__file__).parent
+    for case, (cname, nsamp) in ENCODE_CASES.items():
+        if args.only and case not in args.only:
+            continue
+        out = gen_encode_case(cname, mods, args.seed, nsamp)
+        path = outdir / f"golden_{case}.npz"
+        np.savez_compressed(path, **out)
+        print(f"{case}: wrote {path} ({path.stat().st_size/1e3:.0f} kB); latent {out['latent'].shape}")
     for case, (cname, B, Tv, Tt, ns, nf, lsd, wn, taps) in CASES.items():
         if args.only and case not in args.only:
             continue

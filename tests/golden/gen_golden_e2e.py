@@ -156,6 +156,7 @@ def main():
 
     # ---- end to end: voice state from an audio tensor, exported, then generate_audio
     audio = torch.randn(1, 24000 * 1, generator=g) * 0.1  # 1 s of noise as the "voice"
+    out["e2e_audio"] = audio.numpy()
     vstate = model.get_state_for_audio_prompt(audio)
     R.export_model_state(vstate, OUT / "e2e_voice.safetensors")
     text = "Hello world. This is a test, of the pocket system!"

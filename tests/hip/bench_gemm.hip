@@ -14,7 +14,7 @@ static double bench(const char *name, int M, int N, int K, int ntaps, hipStream_
   a.W = buf; a.X = buf + wsz; a.Y = buf + wsz + 2 * xsz; a.Xdstride = ntaps > 1 ? xsz : 0;
   int *par = (int *)(buf + wsz + 2 * xsz + ysz);
   a.par = ntaps > 1 ? par : nullptr;
-  a.NT = NT; a.KF = KF; a.CF = CF; a.ntaps = ntaps; a.XF = CF; a.MT = MT; a.M = M; a.T = 16; a.epi = EPI_STORE; a.YF = NT;
+  a.NT = NT; a.KF = KF; a.CF = CF; a.ntaps = ntaps; a.XF = CF; a.MT = MT; a.M = M; a.T = 16; a.epi = EPI_STORE; a.YF = NT; a.xstride = 1; a.halo = ntaps - 1;
   dim3 grid(cdiv(NT, TN * WN), cdiv(MT, TM * WM));
   for (int i = 0; i < 5; ++i) gemm_kernel<TN, TM, WK, WN, WM, PRE_NONE><<<grid, 64 * WK * WN * WM, 0, st>>>(a);
   hipStreamSynchronize(st);

@@ -21,7 +21,7 @@ static void run(std::vector<Res> &out, int M, int N, int K, int ntaps, int T) {
   GemmArgs a; memset(&a, 0, sizeof a);
   a.W = g_buf; a.X = g_buf + wsz; a.Y = g_buf + wsz + 2 * xsz; a.Xdstride = ntaps > 1 ? xsz : 0;
   a.par = ntaps > 1 ? (int *)(g_buf + wsz + 2 * xsz + ysz) : nullptr;
-  a.NT = NT; a.KF = KF; a.CF = CF; a.ntaps = ntaps; a.XF = CF; a.MT = MT; a.M = M; a.T = T; a.epi = EPI_STORE; a.YF = NT;
+  a.NT = NT; a.KF = KF; a.CF = CF; a.ntaps = ntaps; a.XF = CF; a.MT = MT; a.M = M; a.T = T; a.epi = EPI_STORE; a.YF = NT; a.xstride = 1; a.halo = ntaps - 1;
   dim3 grid(cdiv(NT, TN * WN), cdiv(MT, TM * WM));
   auto launch = [&] { gemm_kernel<TN, TM, WK, WN, WM, PRE_NONE><<<grid, 64 * WK * WN * WM, 0, g_st>>>(a); };
   for (int i = 0; i < 3; ++i) launch();
@@ -43,7 +43,7 @@ static void run_lds(std::vector<Res> &out, int M, int N, int K, int ntaps, int T
   GemmArgs a; memset(&a, 0, sizeof a);
   a.W = g_buf; a.X = g_buf + wsz; a.Y = g_buf + wsz + 2 * xsz; a.Xdstride = ntaps > 1 ? xsz : 0;
   a.par = ntaps > 1 ? (int *)(g_buf + wsz + 2 * xsz + ysz) : nullptr;
-  a.NT = NT; a.KF = KF; a.CF = CF; a.ntaps = ntaps; a.XF = CF; a.MT = MT; a.M = M; a.T = T; a.epi = EPI_STORE; a.YF = NT;
+  a.NT = NT; a.KF = KF; a.CF = CF; a.ntaps = ntaps; a.XF = CF; a.MT = MT; a.M = M; a.T = T; a.epi = EPI_STORE; a.YF = NT; a.xstride = 1; a.halo = ntaps - 1;
   dim3 grid(cdiv(NT, BNT), cdiv(MT, BMT));
   auto launch = [&] { gemm_lds_kernel<BMT, BNT, KC, PRE_NONE><<<grid, 256, 0, g_st>>>(a); };
   for (int i = 0; i < 3; ++i) launch();

@@ -48,7 +48,7 @@ static void test_gemm(int M, int N, int K, int cfg) {
   float *yfm = dzero<float>((size_t)MT * NT * 256), *dY = dzero<float>((size_t)M * NT * 16);
   to_fm_kernel<<<cdiv((long)MT * KF * 64, 256), 256>>>(dX, xfm, M, K, MT);
   long tot = (long)NT * KF * 256;
-  pack_weight_kernel<<<cdiv(tot, 256), 256>>>(dW, wp, N, K, 1, 0, 0, 0, 0, KF, tot, nullptr);
+  pack_weight_kernel<<<cdiv(tot, 256), 256>>>(dW, wp, N, K, 1, 0, 0, 0, 0, KF, tot, nullptr, K);
   pack_bias_kernel<<<cdiv(NT * 16, 256), 256>>>(db, bp, N, 0, 0, 0, NT * 16);
   GemmArgs a; memset(&a, 0, sizeof(a));
   a.W = wp; a.bias = bp; a.NT = NT; a.KF = KF; a.CF = KF; a.ntaps = 1; a.X = xfm; a.XF = KF; a.MT = MT; a.M = M; a.T = 16;
@@ -95,10 +95,10 @@ static void test_conv(int B, int T, int C, int N, int ntaps, int cfg) {
   to_fm_kernel<<<cdiv((long)MT * CF * 64, 256), 256>>>(dXc, xfm + xs, M, C, MT);
   to_fm_kernel<<<cdiv((long)MT * CF * 64, 256), 256>>>(dXp, xfm, M, C, MT);
   long tot = (long)NT * KF * 256;
-  pack_weight_kernel<<<cdiv(tot, 256), 256>>>(dW, wp, N, C, ntaps, 0, 0, 0, 0, KF, tot, nullptr);
+  pack_weight_kernel<<<cdiv(tot, 256), 256>>>(dW, wp, N, C, ntaps, 0, 0, 0, 0, KF, tot, nullptr, C);
   pack_bias_kernel<<<cdiv(NT * 16, 256), 256>>>(db, bp, N, 0, 0, 0, NT * 16);
   GemmArgs a; memset(&a, 0, sizeof(a));
-  a.W = wp; a.bias = bp; a.NT = NT; a.KF = KF; a.CF = CF; a.ntaps = ntaps; a.X = xfm; a.Xdstride = xs; a.XF = CF; a.MT = MT; a.M = M; a.T = T; a.par = par;
+  a.W = wp; a.bias = bp; a.NT = NT; a.KF = KF; a.CF = CF; a.ntaps = ntaps; a.X = xfm; a.Xdstride = xs; a.XF = CF; a.MT = MT; a.M = M; a.T = T; a.par = par; a.xstride = 1; a.halo = ntaps - 1;
   a.epi = EPI_STORE; a.Y = yfm; a.YF = NT;
   if (cfg >= 100) {
     dim3 grid(cdiv(a.NT, 4), cdiv(a.MT, cfg == 100 ? 8 : 4));
@@ -145,7 +145,7 @@ static void test_gemm_lnfold(int M, int N, int K, int cfg) {
   float *yfm = dzero<float>((size_t)MT * NT * 256), *dY = dzero<float>((size_t)M * NT * 16);
   to_fm_kernel<<<cdiv((long)MT * KF * 64, 256), 256>>>(dX, xfm, M, K, MT);
   long tot = (long)NT * KF * 256;
-  pack_weight_kernel<<<cdiv(tot, 256), 256>>>(dW, wp, N, K, 1, 0, 0, 0, 0, KF, tot, dg);
+  pack_weight_kernel<<<cdiv(tot, 256), 256>>>(dW, wp, N, K, 1, 0, 0, 0, 0, KF, tot, dg, K);
   fold_ln_kernel<<<N, 64>>>(dW, dg, db, dbias, ls, lc, N, K, 0);
   GemmArgs a; memset(&a, 0, sizeof(a));
   a.W = wp; a.NT = NT; a.KF = KF; a.CF = KF; a.ntaps = 1; a.X = xfm; a.XF = KF; a.MT = MT; a.M = M; a.T = 16;

@@ -123,3 +123,32 @@ def test_cli_generate_writes_wav(tmp_path):
         assert w.getnchannels() == 1 and w.getframerate() == 24000 and w.getsampwidth() == 2
         n = w.getnframes()
     assert n >= 1920 + 4800  # at least one frame + 200 ms of silence
+
+
+def test_voice_state_from_audio_matches_reference(model, fx):
+    """`get_state_for_audio_prompt(audio tensor)`: Mimi encoder + speaker projection + bos_before_voice +
+    prefill on the GPU against the voice state the reference produced from the same audio and exported with
+    `export_model_state` (tts_model.py:874-899)."""
+    import safetensors.torch
+
+    ref = safetensors.torch.load_file(str(G / "e2e_voice.safetensors"))
+    state = model.get_state_for_audio_prompt(torch.from_numpy(fx["e2e_audio"]))
+    for name, st in state.items():
+        rc = ref[f"{name}/cache"]
+        T = int(st["offset"][0])
+        assert T == int(ref[f"{name}/offset"][0]) == 14  # 13 frames + bos_before_voice
+        assert np.abs(st["cache"][:, :, :T].cpu().numpy() - rc[:, :, :T].numpy()).max() < 2e-4
+    # and the state drives generation exactly like the file-loaded one
+    wav = model.generate_audio(state, fx["meta"]["text"], frames_after_eos=2)
+    assert wav.shape[0] == fx["e2e_wav_temp0"].shape[0]
+    assert np.abs(wav.numpy() - fx["e2e_wav_temp0"]).max() < 5e-4
+
+
+def test_voice_state_from_wav_file(model, fx, tmp_path):
+    import wave
+
+    pcm = (np.clip(fx["e2e_audio"][0], -1, 1) * 32767).astype(np.int16)
+    with wave.open(str(tmp_path / "v.wav"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(24000); w.writeframes(pcm.tobytes())
+    state = model.get_state_for_audio_prompt(tmp_path / "v.wav")
+    assert int(state["transformer.layers.0.self_attn"]["offset"][0]) == 14

@@ -263,3 +263,35 @@ def _run_pipeline_mode(eng, mode, B, Tp, ns, emb, ref):
         for i in range(ns):
             assert np.array_equal(got[i], ref[i]), (mode, rep, i)
     pipe.close()
+
+
+@pytest.mark.parametrize("case", ["encode_tiny", "encode_en100m"])
+def test_voice_encode_vs_golden(golden, case):
+    """Voice-prompt encode path on the GPU (SEANet encoder with strided / zero-padded convs, whole-sequence
+    windowed encoder transformer, replicate-padded downsample, speaker projection) against the reference's
+    `MimiModel.encode_to_latent` (mimi.py:96-119) and `_encode_audio` (tts_model.py:379-388)."""
+    g = golden(case)
+    m = g["meta"]
+    eng = get_engine(m["config"], m["seed"])
+    lat, cond = eng.encode_voice(dev(g["audio"][0, 0]))
+    torch.cuda.synchronize()
+    ref_lat = g["latent"][0].T  # [frames, ldim]
+    assert lat.shape == ref_lat.shape
+    assert _maxerr(lat.cpu().numpy(), ref_lat) < ATOL
+    assert _maxerr(cond.cpu().numpy(), g["conditioning"][0]) < ATOL
+
+
+def test_voice_encode_long_audio_vs_oracle():
+    """4.3 s prompt: the encoder transformer runs over 864 positions with its 40-position window (tiny config)
+    and several key splits; oracle = numpy restatement."""
+    from oracle import np_oracle as O
+
+    cfg, W = synth_weights("tiny")
+    eng = get_engine("tiny")
+    rng = np.random.default_rng(5)
+    audio = (rng.standard_normal(24000 * 4 + 7000) * 0.2).astype(np.float32)
+    ref = O.VoiceEncoder(cfg, W).conditioning(audio[None, None])[0]
+    _, cond = eng.encode_voice(dev(audio))
+    torch.cuda.synchronize()
+    assert cond.shape == ref.shape == (54, eng.D)
+    assert _maxerr(cond.cpu().numpy(), ref) < ATOL

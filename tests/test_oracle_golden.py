@@ -108,3 +108,21 @@ def test_golden_covers_first_frame_zero_state(golden):
     """Frame 0 exercises the zero-initialised `previous`/`partial` carries."""
     g = golden("tiny_b2")
     assert "tap_upsample" in g and "tap_seanet0" in g and g["tap_seanet0"].shape[0] == 3
+
+
+@pytest.mark.parametrize("case", ["encode_tiny", "encode_en100m"])
+def test_voice_encoder_matches_reference(golden, case):
+    """SEANet encoder + encoder transformer + replicate-padded downsample + speaker projection against
+    the reference's `MimiModel.encode_to_latent` (mimi.py:96-119)."""
+    g = golden(case)
+    m = g["meta"]
+    cfg, W = synth_weights(m["config"], m["seed"])
+    enc = O.VoiceEncoder(cfg, W)
+    taps = {}
+    lat = enc.encode_to_latent(g["audio"], taps)
+    assert lat.shape == g["latent"].shape
+    for k, v in taps.items():
+        if "tap_" + k in g:
+            assert _maxerr(v, g["tap_" + k]) < ATOL, k
+    assert _maxerr(lat, g["latent"]) < ATOL
+    assert _maxerr(enc.conditioning(g["audio"]), g["conditioning"]) < ATOL
