@@ -68,6 +68,10 @@ int ptts_lm_state_export(ptts_lm_state *s, int32_t layer, float *d_cache, int32_
 /* dst <- src (replaces copy.deepcopy(model_state), tts_model.py:637-638); src batch 1 broadcasts.
  * The clone starts a new generation: its pending input latent is BOS (tts_model.py:748-753). */
 int ptts_lm_state_copy(ptts_lm_state *dst, const ptts_lm_state *src, void *stream);
+/* row `row` of dst <- the single sequence of src (batch 1): assembles a batch from utterances prefilled one by
+ * one with different prompt lengths; every kernel reads per-row offsets, so rows need not be in sync (the
+ * reference requires equal offsets across the batch: transformer.py:12-13). */
+int ptts_lm_state_copy_row(ptts_lm_state *dst, int32_t row, const ptts_lm_state *src, void *stream);
 /* offsets of all rows to host (transformer.py:14 `.item()`; synchronises the stream) */
 int ptts_lm_state_offsets(ptts_lm_state *s, int32_t *h_offsets, void *stream);
 

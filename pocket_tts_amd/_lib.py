@@ -46,6 +46,7 @@ PROTOTYPES = {
     "ptts_lm_state_import": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, _P]),
     "ptts_lm_state_export": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P]),
     "ptts_lm_state_copy": (C.c_int, [_P, _P, _P]),
+    "ptts_lm_state_copy_row": (C.c_int, [_P, C.c_int32, _P, _P]),
     "ptts_lm_state_offsets": (C.c_int, [_P, C.POINTER(C.c_int32), _P]),
     "ptts_lm_prefill": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
     "ptts_lm_decode_step": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_float, _P, _P, _P, _P]),

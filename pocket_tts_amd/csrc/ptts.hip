@@ -786,6 +786,28 @@ extern "C" int ptts_lm_state_copy(ptts_lm_state *dst, const ptts_lm_state *src, 
   return 0;
 }
 
+// Row `row` of dst <- the single sequence of src (B = 1): KV rows, offset and a BOS pending input.  Lets a batch
+// be assembled from utterances prefilled one by one with different prompt lengths (per-row offsets).
+extern "C" int ptts_lm_state_copy_row(ptts_lm_state *dst, int32_t row, const ptts_lm_state *src, void *stream) {
+  if (dst->e != src->e) return fail(-1, "states belong to different engines");
+  if (src->B != 1 || row < 0 || row >= dst->B) return fail(-1, "copy_row: src must have batch 1 and row must be in range");
+  const ptts_config &c = dst->e->cfg;
+  hipStream_t st = S(dst->e, stream);
+  const int T = src->h_off[0];
+  if (T > dst->cap) return fail(-5, "copy_row: destination capacity too small");
+  for (int pl = 0; pl < c.num_layers * 2; ++pl)
+    for (int h = 0; h < c.num_heads; ++h) {
+      const float *sp = src->kv + ((size_t)pl * c.num_heads + h) * src->cap * 64;
+      float *dp = dst->kv + (((size_t)pl * dst->B + row) * c.num_heads + h) * dst->cap * 64;
+      if (T) HIPCHK(hipMemcpyAsync(dp, sp, (size_t)T * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+  dst->h_off[row] = T;
+  set_int_kernel<<<1, 64, 0, st>>>(dst->offset + row, 1, T);
+  fill_kernel<<<cdiv(c.ldim, 256), 256, 0, st>>>(dst->lat_prev + (size_t)row * c.ldim, (long)c.ldim, NAN);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int ptts_lm_state_offsets(ptts_lm_state *s, int32_t *h, void *stream) {
   hipStream_t st = S(s->e, stream);
   HIPCHK(hipMemcpyAsync(h, s->offset, s->B * sizeof(int), hipMemcpyDeviceToHost, st));

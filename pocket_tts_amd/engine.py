@@ -88,6 +88,10 @@ class LMState:
         e.sync()
         return out
 
+    def copy_row_from(self, row: int, src: "LMState"):
+        """row `row` <- the single sequence of `src` (batch 1); rows may have different lengths"""
+        _lib.check(self.engine.lib.ptts_lm_state_copy_row(self.handle, row, src.handle, self.engine._sp))
+
     def copy_from(self, src: "LMState"):
         _lib.check(self.engine.lib.ptts_lm_state_copy(self.handle, src.handle, self.engine._sp))
 

@@ -194,6 +194,106 @@ class TTSModel:
             effective = frames_after_eos if frames_after_eos is not None else guess
             yield from self._generate_audio_stream_short_text(model_state, chunk, effective, copy_state)
 
+    @torch.no_grad()
+    def generate_audio_batch(self, model_states, texts, frames_after_eos: int | None = None) -> list:
+        """Generate several utterances concurrently on one GPU (not in the reference, which is batch 1 and
+        requires equal cache offsets across a batch: tts_model.py:491-492, transformer.py:12-13).
+
+        `model_states`: one voice state or a list (one per text); `texts`: list of short texts (each must
+        fit one chunk of `MAX_TOKEN_PER_CHUNK` tokens; split longer texts first).  Every utterance is prefilled
+        on its own (voice + text lengths differ), placed in one row of a batch state, and all rows are decoded
+        in lock-step with per-row positions; per-row EOS bookkeeping follows tts_model.py:756-768.  With
+        temp == 0 each waveform equals the single-utterance result; with temp > 0 rows draw independent noise
+        (the reference's sequential use of the global generator cannot be reproduced across a batch).
+        Returns a list of fp32 CPU tensors."""
+        from .engine import StepPipeline
+
+        eng = self.engine
+        B = len(texts)
+        if not isinstance(model_states, (list, tuple)):
+            model_states = [model_states] * B
+        if len(model_states) != B or B == 0:
+            raise ValueError("need one voice state per text")
+        toks, gens, faes, t0s = [], [], [], []
+        for text, ms_ in zip(texts, model_states):
+            prepared, guess = prepare_text_prompt(text, self.pad_with_spaces_for_short_inputs, self.remove_semicolons)
+            # the reference tokenises the chunk text as split_into_best_sentences returns it (stripped)
+            chunk = split_into_best_sentences(self.tokenizer.encode, self.tokenizer.sp, text, 10 ** 9,
+                                              self.pad_with_spaces_for_short_inputs, self.remove_semicolons)
+            if len(chunk) != 1:
+                raise ValueError("generate_audio_batch takes single-chunk texts")
+            ids = self.tokenizer.encode(chunk[0])
+            if len(ids) > MAX_TOKEN_PER_CHUNK:
+                raise ValueError(f"text has {len(ids)} tokens; split it into chunks of <= {MAX_TOKEN_PER_CHUNK}")
+            _, guess = prepare_text_prompt(chunk[0], self.pad_with_spaces_for_short_inputs, self.remove_semicolons)
+            fae = frames_after_eos if frames_after_eos is not None else (
+                self.model_recommended_frames_after_eos if self.model_recommended_frames_after_eos is not None else guess + 2)
+            toks.append(torch.tensor(ids, dtype=torch.long)[None, :])
+            gens.append(estimate_max_gen_len(len(ids), self.config.mimi.frame_rate))
+            faes.append(fae)
+            t0s.append(_state_current_end(ms_))
+        steps_max = max(gens)
+        cap = max(t + tk.shape[1] for t, tk in zip(t0s, toks)) + steps_max + 1
+        batch = eng.new_lm_state(B, cap)
+        ms = eng.new_mimi_state(B)
+        for b in range(B):  # per-utterance prefill (lengths differ), then into row b
+            one = eng.new_lm_state(1, t0s[b] + toks[b].shape[1])
+            _import_lm_state(eng, one, model_states[b], t0s[b])
+            eng.lm_prefill(one, eng.embed_text(toks[b]))
+            batch.copy_row_from(b, one)
+            eng.sync()
+            one.close()
+        use_noise = self.temp > 0
+        if use_noise:
+            batch.set_noise(self.temp, int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
+        pipe = StepPipeline(eng, batch, ms, None, self.lsd_decode_steps, float(self.eos_threshold), mode="hostsync")
+        eos_step = [None] * B
+        n_emit = [None] * B          # frames to keep for row b (decided when its loop would break)
+        chunks = [[] for _ in range(B)]
+        emitted = 0
+        try:
+            for step in range(steps_max):
+                pipe.lm_step_async()
+                flags = pipe.wait_flags(step)
+                for b in range(B):
+                    if n_emit[b] is not None:
+                        continue
+                    if step >= gens[b]:
+                        n_emit[b] = gens[b]           # max length without EOS (warning path, tts_model.py:770-775)
+                        continue
+                    if bool(flags[b].item()) and eos_step[b] is None:
+                        eos_step[b] = step
+                    if eos_step[b] is not None and step >= eos_step[b] + faes[b]:
+                        n_emit[b] = step              # the break-step latent is not decoded
+                if all(n is not None and n <= step for n in n_emit):
+                    break
+                # collect the previous frame before its pinned buffer is reused two frames later
+                if emitted >= 2:
+                    self._collect(pipe, emitted - 2, chunks, n_emit)
+                pipe.decode_async(step)
+                emitted += 1
+            for f in range(max(0, emitted - 2), emitted):
+                self._collect(pipe, f, chunks, n_emit)
+        finally:
+            pipe.close()
+            batch.close()
+            ms.close()
+        out = []
+        for b in range(B):
+            n = n_emit[b] if n_emit[b] is not None else gens[b]
+            if eos_step[b] is None:
+                logger.warning("Maximum generation length reached without EOS, this very often indicates an error.")
+            out.append(torch.cat(chunks[b][:n]) if n > 0 else torch.zeros(0))
+        return out
+
+    @staticmethod
+    def _collect(pipe, frame, chunks, n_emit):
+        pipe.ev[frame & 1].synchronize()
+        pcm = pipe.pcm_of(frame)
+        for b in range(len(chunks)):
+            if n_emit[b] is None or frame < n_emit[b]:
+                chunks[b].append(pcm[b].clone())
+
     def _draw_noise(self, out: torch.Tensor):
         """Same draws as the reference CPU path (flow_lm.py:131-137): torch's global CPU generator."""
         std = self.temp ** 0.5

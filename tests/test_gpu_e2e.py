@@ -152,3 +152,27 @@ def test_voice_state_from_wav_file(model, fx, tmp_path):
         w.setnchannels(1); w.setsampwidth(2); w.setframerate(24000); w.writeframes(pcm.tobytes())
     state = model.get_state_for_audio_prompt(tmp_path / "v.wav")
     assert int(state["transformer.layers.0.self_attn"]["offset"][0]) == 14
+
+
+def test_generate_audio_batch_matches_single_utterances(model, fx):
+    """Mixed-length batch (different texts, hence different prompt lengths and per-row cache offsets, different
+    EOS steps and frame counts) against one-by-one generation at temp 0."""
+    state = model.get_state_for_audio_prompt(G / "e2e_voice.safetensors")
+    texts = ["Hello world. This is a test.", "ok", "This is a longer sentence, with several clauses, to test it.",
+             "How are you today?", "Short one."]
+    singles = [model.generate_audio(state, t) for t in texts]
+    batch = model.generate_audio_batch(state, texts)
+    assert len(batch) == len(texts)
+    lens = [w.shape[0] for w in singles]
+    assert len(set(lens)) > 1  # the rows really end at different frames
+    for t, a, b in zip(texts, singles, batch):
+        assert a.shape == b.shape, (t, a.shape, b.shape)
+        assert np.abs(a.numpy() - b.numpy()).max() < 5e-4, t
+
+
+def test_generate_audio_batch_validates_inputs(model):
+    state = model.get_state_for_audio_prompt(G / "e2e_voice.safetensors")
+    with pytest.raises(ValueError):
+        model.generate_audio_batch([state], ["a", "b"])
+    with pytest.raises(ValueError):
+        model.generate_audio_batch(state, ["   "])
