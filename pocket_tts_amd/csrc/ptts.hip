@@ -397,10 +397,15 @@ static void launch_ln(hipStream_t st, const float *X, long xds, int XF, float *Y
   layernorm_kernel<<<MT, 256, 0, st>>>(a);
 }
 
+static int attn_wave_target() {
+  static int t = [] { const char *v = getenv("PTTS_ATTN_WAVES"); return v ? atoi(v) : 1024; }();
+  return t;
+}
 static int attn_splits(int base, int max_tiles) {
-  // one wave per (sequence, head, query block, split): aim for >= 4096 waves (16 per CU) so that the KV
-  // stream has enough loads in flight; a split never gets less than ~2 key tiles
-  int s = std::max(1, cdiv(4096, std::max(1, base)));
+  // one wave per (sequence, head, query block, split).  Keys are split only until ~1024 waves exist (measured at
+  // batch 64: 1024 -> 1.139 ms/step, 4096 -> 1.168, 8192 -> 1.211; more splits only add combine launches);
+  // a split never gets less than ~2 key tiles.  PTTS_ATTN_WAVES overrides the target for experiments.
+  int s = std::max(1, cdiv(attn_wave_target(), std::max(1, base)));
   s = std::min(s, std::max(1, max_tiles / 2));
   return std::max(1, std::min(s, max_tiles));
 }

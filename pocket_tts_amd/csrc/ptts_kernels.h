@@ -261,7 +261,9 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
   const int halo = a.halo;
   // Software pipeline over chunks of U k-fragments: the 1 KiB operand loads of chunk c+1 are issued before the
   // MFMAs of chunk c, into a second register set, so the matrix pipe works while the next operands fly.
-  constexpr int U = (TN * TM == 1) ? 8 : (TN * TM <= 4 && WK > 1) ? 4 : 2;
+  // decode (K-split) tiles: as many fragments per round as the register file allows, so that a wave needs
+  // few serialized HBM round trips for its cold weight stream
+  constexpr int U = (TN * TM == 1) ? 8 : (TN * TM == 2 && WK > 1) ? 8 : (TN * TM <= 4 && WK > 1) ? 4 : 2;
   auto load_chunk = [&](auto uc, int kf, f32x4 (*w)[TN], f32x4 (*x)[TM]) {
     constexpr int UU = decltype(uc)::value;
 #pragma unroll
