@@ -939,6 +939,7 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
   a = mk_gemm(e->head, sc.x, DF, MT, B);
   a.epi = EPI_HEAD; a.Y = s->ce; a.YF = FDF; a.head_nt = FDF; a.eos_thr = eos_thr;
   a.eos_logit = s->eos_logit; a.is_eos = s->is_eos;
+  a.eos_logit2 = d_eos_logit; a.is_eos2 = d_is_eos;  // caller's buffers are written by the epilogue itself
   launch_gemm(st, a, PRE_LNFOLD);
   const int AF = e->adaln.NT;
   for (int i = 0; i < lsd_steps; ++i) {
@@ -973,19 +974,15 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
     SITE("flow.final");
     a = mk_gemm(e->fin, s->fh, FDF, MT, B);
     a.epi = EPI_LATENT; a.lat = s->lat; a.ldim = c.ldim; a.inv_steps = 1.0f / (float)lsd_steps; a.Y = s->latfm; a.YF = LF;
+    if (i == lsd_steps - 1) { a.lat_out1 = s->lat_prev; a.lat_out2 = d_latent_out; }  // next step's input + caller's copy
     launch_gemm(st, a, PRE_NONE);
   }
   SITE("lm.tail");
   {
-    ProfScope ps(st, "step_tail", 8.0 * B * c.ldim, 0);
-    add_int_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->offset, B, 1);
-    add_int_kernel<<<1, 64, 0, st>>>(s->rng_ctr, 1, 1);
+    ProfScope ps(st, "step_tail", 8.0 * B, 0);
+    step_tail_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->offset, B, 1, s->rng_ctr);
   }
   SITE("");
-  hipMemcpyAsync(s->lat_prev, s->lat, (size_t)B * c.ldim * sizeof(float), hipMemcpyDeviceToDevice, st);
-  if (d_latent_out) hipMemcpyAsync(d_latent_out, s->lat, (size_t)B * c.ldim * sizeof(float), hipMemcpyDefault, st);
-  if (d_eos_logit) hipMemcpyAsync(d_eos_logit, s->eos_logit, B * sizeof(float), hipMemcpyDefault, st);
-  if (d_is_eos) hipMemcpyAsync(d_is_eos, s->is_eos, B, hipMemcpyDefault, st);  // outputs may be pinned host memory
   return 0;
 }
 
@@ -1170,8 +1167,7 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
   SITE("mimi.tail");
   {
     ProfScope ps(st, "step_tail", 8.0 * B, 0);
-    add_int_kernel<<<1, 64, 0, st>>>(s->frame, 1, 1);
-    add_int_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->offset, B, st16);
+    step_tail_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->offset, B, st16, s->frame);
   }
   SITE("");
   return 0;

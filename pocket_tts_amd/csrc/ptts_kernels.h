@@ -90,12 +90,13 @@ struct GemmArgs {
   const float *rope;  // [M][32][2] (cos, sin) of pos * freq, built once per step by rope_table_kernel
   int H, Tq, QB, cap, ring;
   // EPI_HEAD
-  float *eos_logit;
-  uint8_t *is_eos;
+  float *eos_logit, *eos_logit2;  // state copy, caller's copy (device or pinned host)
+  uint8_t *is_eos, *is_eos2;
   float eos_thr;
   int head_nt;  // n-tile holding the EOS row
   // EPI_LATENT
   float *lat;  // plain [M][ldim], updated in place
+  float *lat_out1, *lat_out2;  // optional extra copies of the updated latent (state's next input, caller's buffer)
   float inv_steps;
   int ldim;
   // EPI_CONVTR
@@ -176,8 +177,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 acc, int 
       if (nt < a.head_nt) {
         *(f32x4 *)(a.Y + (((size_t)mt * a.YF + nt) * 64 + lane) * 4) = acc;
       } else if (g == 0 && m < a.M) {
+        const uint8_t fl = acc.x > a.eos_thr ? 1 : 0;
         if (a.eos_logit) a.eos_logit[m] = acc.x;
-        if (a.is_eos) a.is_eos[m] = acc.x > a.eos_thr ? 1 : 0;
+        if (a.eos_logit2) a.eos_logit2[m] = acc.x;
+        if (a.is_eos) a.is_eos[m] = fl;
+        if (a.is_eos2) a.is_eos2[m] = fl;
       }
     } break;
     case EPI_LATENT: {
@@ -187,6 +191,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 acc, int 
         float *p = a.lat + (size_t)m * a.ldim + n0;
         v = *(f32x4 *)p + acc * a.inv_steps;
         *(f32x4 *)p = v;
+        if (a.lat_out1) *(f32x4 *)(a.lat_out1 + (size_t)m * a.ldim + n0) = v;
+        if (a.lat_out2) *(f32x4 *)(a.lat_out2 + (size_t)m * a.ldim + n0) = v;
       } else {
         v = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
@@ -800,6 +806,13 @@ __global__ void audio_to_fm_kernel(const float *audio, float *x_fm, int n_valid,
 __global__ void add_int_kernel(int *p, int n, int inc) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] += inc;
+}
+// end-of-step bookkeeping in one launch: offsets of all rows += inc (increment_steps, reference
+// stateful_module.py:19-26) and one scalar counter (noise counter / frame parity) += 1
+__global__ void step_tail_kernel(int *offset, int n, int inc, int *counter) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) offset[i] += inc;
+  if (i == 0 && counter) *counter += 1;
 }
 __global__ void set_int_kernel(int *p, int n, int v) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
