@@ -299,6 +299,7 @@ static void launch_cfg(hipStream_t st, const GemmArgs &a, int pre) {
   switch (pre) {
     case PRE_NONE: gemm_kernel<TN, TM, WK, WN, WM, PRE_NONE><<<grid, block, 0, st>>>(a); break;
     case PRE_LNFOLD: gemm_kernel<TN, TM, WK, WN, WM, PRE_LNFOLD><<<grid, block, 0, st>>>(a); break;
+    case PRE_LNMOD: gemm_kernel<TN, TM, WK, WN, WM, PRE_LNMOD><<<grid, block, 0, st>>>(a); break;
     default: gemm_kernel<TN, TM, WK, WN, WM, PRE_ADDSILU><<<grid, block, 0, st>>>(a); break;
   }
 }
@@ -319,7 +320,7 @@ static int pick_cfg(const GemmArgs &a) {
   const long tiled = (long)cdiv(a.NT, 4) * cdiv(a.MT, 8);
   // many rows (codec convs at batch >= 16): LDS-staged kernel, each operand fragment DMA'd once per workgroup
   // (tests/hip/sweep_gemm.hip: 5-12 % faster than the register-staged tiles on these shapes)
-  if (a.MT >= 256 && a.NT >= 4 && a.KF % 2 == 0 && a.epi != EPI_QKV) return a.NT >= 8 ? 8 : 9;
+  if (a.MT >= 256 && a.NT >= 4 && a.KF % 2 == 0 && a.epi != EPI_QKV && !a.mod_scale) return a.NT >= 8 ? 8 : 9;
   if (a.MT > 4 && tiled >= 192) return a.NT >= 4 ? 3 : a.NT >= 2 ? 4 : 5;
   // few output tiles but a long K (Mimi FFN2 / conv k7 / out_proj at moderate batch): 2x4 tiles per wave,
   // the 4 waves of a workgroup split K -> 4x the workgroups of the 2-D tiling at the same operand reuse
@@ -346,7 +347,7 @@ static void launch_gemm(hipStream_t st, const GemmArgs &a_in, int pre) {
   double bytes = 4.0 * (N * K + M * (double)a.CF * 16 + M * N);
   if (a.epi == EPI_RES || a.epi == EPI_GATE) bytes += 4.0 * M * N;
   const int cfg = pick_cfg(a);
-  ProfScope ps(st, std::string(kCfgName[cfg]) + (pre == PRE_NONE ? "" : pre == PRE_LNFOLD ? "+ln" : "+addsilu"), bytes, 2.0 * M * N * K);
+  ProfScope ps(st, std::string(kCfgName[cfg]) + (pre == PRE_NONE ? "" : pre == PRE_LNFOLD ? "+ln" : pre == PRE_LNMOD ? "+lnmod" : "+addsilu"), bytes, 2.0 * M * N * K);
   switch (cfg) {
     case 0: launch_cfg<1, 1, 8, 1, 1>(st, a, pre); break;  // 8 waves: most bytes in flight per CU for cold weights
     // TM >= 2: 4-wave K split measured >= 8-wave (tests/hip/sweep_gemm.hip)
@@ -956,12 +957,12 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
       const float *shift = s->mod + (size_t)(r * 3 * FDF) * 256;
       const float *scale = shift + (size_t)FDF * 256;
       const float *gate = scale + (size_t)FDF * 256;
-      SITE("flow.res.ln");
-      launch_ln(st, s->fx, 0, FDF, s->fh, FDF, e->res[r].ln_w, e->res[r].ln_b, shift, scale, AF, FDF, 1e-6f, MT, nullptr);
-      SITE("flow.res.l0");
-      a = mk_gemm(e->res[r].l0, s->fh, FDF, MT, B);
+      SITE("flow.res.l0");  // in_ln + AdaLN modulate are applied to the operand on load (PRE_LNMOD)
+      a = mk_gemm(e->res[r].l0, s->fx, FDF, MT, B);
       a.act = ACT_SILU; a.Y = s->f1; a.YF = FDF;
-      launch_gemm(st, a, PRE_NONE);
+      a.lnm_w = e->res[r].ln_w; a.lnm_b = e->res[r].ln_b; a.mod_shift = shift; a.mod_scale = scale; a.modF = AF;
+      a.ln_eps = 1e-6f;  // flow-MLP LayerNorm eps (mlp.py:95)
+      launch_gemm(st, a, PRE_LNMOD);
       SITE("flow.res.l2");
       a = mk_gemm(e->res[r].l2, s->f1, FDF, MT, B);
       a.epi = EPI_GATE; a.R = s->fx; a.RF = FDF; a.G = gate; a.GF = AF; a.Y = s->fx; a.YF = FDF;
@@ -969,13 +970,12 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
     }
     const float *shift = s->mod + (size_t)(c.flow_depth * 3 * FDF) * 256;
     const float *scale = shift + (size_t)FDF * 256;
-    SITE("flow.final.ln");
-    launch_ln(st, s->fx, 0, FDF, s->fh, FDF, nullptr, nullptr, shift, scale, AF, FDF, 1e-6f, MT, nullptr);
-    SITE("flow.final");
-    a = mk_gemm(e->fin, s->fh, FDF, MT, B);
+    SITE("flow.final");  // norm_final (no affine) + modulate on load
+    a = mk_gemm(e->fin, s->fx, FDF, MT, B);
+    a.lnm_w = nullptr; a.lnm_b = nullptr; a.mod_shift = shift; a.mod_scale = scale; a.modF = AF; a.ln_eps = 1e-6f;
     a.epi = EPI_LATENT; a.lat = s->lat; a.ldim = c.ldim; a.inv_steps = 1.0f / (float)lsd_steps; a.Y = s->latfm; a.YF = LF;
     if (i == lsd_steps - 1) { a.lat_out1 = s->lat_prev; a.lat_out2 = d_latent_out; }  // next step's input + caller's copy
-    launch_gemm(st, a, PRE_NONE);
+    launch_gemm(st, a, PRE_LNMOD);
   }
   SITE("lm.tail");
   {

@@ -27,7 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PTTS_ABLATE 0
 #endif
 
-enum { PRE_NONE = 0, PRE_ELU = 1, PRE_ADDSILU = 2, PRE_LNFOLD = 3 };
+enum { PRE_NONE = 0, PRE_ELU = 1, PRE_ADDSILU = 2, PRE_LNFOLD = 3, PRE_LNMOD = 4 };
 enum { EPI_STORE = 0, EPI_RES, EPI_GATE, EPI_QKV, EPI_HEAD, EPI_LATENT, EPI_CONVTR, EPI_PCM };
 enum { ACT_NONE = 0, ACT_GELU, ACT_SILU, ACT_ELU };
 
@@ -71,6 +71,11 @@ struct GemmArgs {
   // per row from the X fragments it loads anyway and finishes  y = rstd (W'x - mean ln_s) + ln_c.
   const float *ln_s, *ln_c;
   float ln_eps;
+  // PRE_LNMOD: AdaLN-modulated LayerNorm applied to the operand on load (flow MLP, reference mlp.py:107-109,
+  // 127-129): x' = (LN(x) * lnm_w + lnm_b) * (1 + scale[m][k]) + shift[m][k]; row statistics come from a
+  // pre-pass over the (short) rows.  lnm_w == null: no affine (final layer).
+  const float *lnm_w, *lnm_b, *mod_shift, *mod_scale;
+  int modF;
   int epi, act;
   // output FM view
   float *Y;
@@ -259,6 +264,36 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
     tin[j] = t;
     bT[j] = row - t;
   }
+  float lmu[TM], lrs[TM];  // PRE_LNMOD row statistics
+  if constexpr (PRE == PRE_LNMOD) {
+    // pre-pass over the (short, L2-resident) rows: 8 independent loads in flight per batch
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      float s1 = 0.f, s2 = 0.f;
+      const float *xr = Xc + ((size_t)mtc[j] * a.XF * 64 + lane) * 4;
+      int kf = 0;
+      for (; kf + 8 <= a.KF; kf += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = *(const f32x4 *)(xr + (size_t)(kf + q) * 256);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          s1 += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+          s2 += (v[q].x * v[q].x + v[q].y * v[q].y) + (v[q].z * v[q].z + v[q].w * v[q].w);
+        }
+      }
+      for (; kf < a.KF; ++kf) {
+        const f32x4 v = *(const f32x4 *)(xr + (size_t)kf * 256);
+        s1 += (v.x + v.y) + (v.z + v.w);
+        s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+      s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+      const float invK = 1.0f / (float)(a.KF * 16);
+      lmu[j] = s1 * invK;
+      lrs[j] = 1.0f / sqrtf(fmaxf(s2 * invK - lmu[j] * lmu[j], 0.f) + a.ln_eps);
+    }
+  }
   int tap = 0, cf = k0;
   if (a.ntaps > 1) {
     tap = k0 / a.CF;
@@ -312,6 +347,16 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
     for (int u = 0; u < UU; ++u) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) x[u][j] = pre4<PRE>(x[u][j], a.prevec, kf + u, lane);
+      if constexpr (PRE == PRE_LNMOD) {
+        const int k = 16 * (kf + u) + 4 * (lane >> 4);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          f32x4 v = (x[u][j] - lmu[j]) * lrs[j];
+          if (a.lnm_w) v = v * *(const f32x4 *)(a.lnm_w + k) + *(const f32x4 *)(a.lnm_b + k);
+          const size_t mi = (((size_t)mtc[j] * a.modF + kf + u) * 64 + lane) * 4;
+          x[u][j] = v * (1.0f + *(const f32x4 *)(a.mod_scale + mi)) + *(const f32x4 *)(a.mod_shift + mi);
+        }
+      }
       if constexpr (PRE == PRE_LNFOLD) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
