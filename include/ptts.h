@@ -128,6 +128,16 @@ int ptts_graph_capture_pipelined(ptts_engine *e, ptts_lm_state *s, ptts_mimi_sta
 int ptts_graph_launch(ptts_graph *g, void *stream);
 void ptts_graph_destroy(ptts_graph *g);
 
+/* ---- tile autotuning (no reference counterpart: torch picks its CPU kernels at dispatch time).
+ * Runs one FlowLM step + one codec frame of `batch` rows on scratch states and, for every GEMM shape on the
+ * path, times each valid tile configuration (cache flushed before every timed launch) and remembers the
+ * fastest for this engine.  Call it before capturing graphs for that batch; shapes never tuned use the static
+ * heuristic.  Results are numerically equivalent up to fp32 summation order.  Synchronises.
+ * ptts_tune_log: one text line per tuned shape (valid until the next tune/clear). */
+int ptts_tune(ptts_engine *e, int32_t batch, void *stream);
+const char *ptts_tune_log(ptts_engine *e);
+void ptts_tune_clear(ptts_engine *e);
+
 /* ---- utilities */
 int ptts_sync(ptts_engine *e, void *stream);
 void *ptts_engine_stream(ptts_engine *e);

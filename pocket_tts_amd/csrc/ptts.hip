@@ -99,6 +99,7 @@ struct ptts_engine {
   std::vector<TrLayer> enc_tr;
   float *zeros = nullptr;
   int64_t lm_bytes = 0, mimi_bytes = 0;
+  struct Tuner *tuner = nullptr;
 };
 
 struct Scratch {
@@ -333,24 +334,33 @@ static int pick_cfg(const GemmArgs &a) {
   while (tm > 1 && (long)a.NT * cdiv(a.MT, tm) < 256) tm >>= 1;
   return tm == 4 ? 2 : tm == 2 ? 1 : 0;
 }
-static const char *const kCfgName[10] = {"gemm<1,1,8,1,1>", "gemm<1,2,4,1,1>", "gemm<1,4,4,1,1>", "gemm<2,4,1,2,2>",
-                                        "gemm<2,4,1,1,4>", "gemm<1,4,1,1,4>", "gemm<1,1,1,1,4>", "gemm<2,4,4,1,1>",
-                                         "gemm_lds<4,8,2>", "gemm_lds<4,4,2>"};
+static constexpr int kNumCfg = 16;
+static const char *const kCfgName[kNumCfg] = {
+    "gemm<1,1,8,1,1>", "gemm<1,2,4,1,1>", "gemm<1,4,4,1,1>", "gemm<2,4,1,2,2>", "gemm<2,4,1,1,4>", "gemm<1,4,1,1,4>",
+    "gemm<1,1,1,1,4>", "gemm<2,4,4,1,1>", "gemm_lds<4,8,2>", "gemm_lds<4,4,2>", "gemm<2,2,4,1,1>", "gemm<1,1,4,1,1>",
+    "gemm_lds<4,2,2>", "gemm<1,2,1,2,2>", "gemm<2,4,2,2,1>", "gemm_lds<8,8,2>"};
+// {TN, TM, WK, WN, WM} of the register-staged configs, {BNT, BMT, 0, 0, 0} of the LDS-staged ones
+static const int kCfgShape[kNumCfg][5] = {{1, 1, 8, 1, 1}, {1, 2, 4, 1, 1}, {1, 4, 4, 1, 1}, {2, 4, 1, 2, 2}, {2, 4, 1, 1, 4},
+                                          {1, 4, 1, 1, 4}, {1, 1, 1, 1, 4}, {2, 4, 4, 1, 1}, {8, 4, 0, 0, 0}, {4, 4, 0, 0, 0},
+                                          {2, 2, 4, 1, 1}, {1, 1, 4, 1, 1}, {2, 4, 0, 0, 0}, {1, 2, 1, 2, 2}, {2, 4, 2, 2, 1},
+                                          {8, 8, 0, 0, 0}};
 
-static thread_local const float *g_zeros = nullptr;  // set by the entry points from the engine
+static bool cfg_valid(int cfg, const GemmArgs &a, int pre) {
+  const int *s = kCfgShape[cfg];
+  if (s[2] == 0) {  // LDS-staged: two k-fragments per stage, plain or LN-folded operand only
+    if (a.KF % 2 || (pre != PRE_NONE && pre != PRE_LNFOLD)) return false;
+    return a.MT >= s[1] && 2 * a.NT >= s[0];
+  }
+  const int tn = s[0] * s[3], tm = s[1] * s[4];
+  if (tm > 1 && tm > 2 * a.MT) return false;  // mostly padding
+  if (tn > 1 && tn > 2 * a.NT) return false;
+  if (s[2] > 1 && a.KF < 2) return false;  // nothing to split
+  return true;
+}
 
-static void launch_gemm(hipStream_t st, const GemmArgs &a_in, int pre) {
-  GemmArgs a = a_in;
-  a.zeros = g_zeros;
-  // algorithmic traffic: weights once + input rows once (x taps re-read from cache, not counted) + output
-  const double K = (double)a.KF * 16, N = (double)a.NT * 16, M = (double)a.M;
-  double bytes = 4.0 * (N * K + M * (double)a.CF * 16 + M * N);
-  if (a.epi == EPI_RES || a.epi == EPI_GATE) bytes += 4.0 * M * N;
-  const int cfg = pick_cfg(a);
-  ProfScope ps(st, std::string(kCfgName[cfg]) + (pre == PRE_NONE ? "" : pre == PRE_LNFOLD ? "+ln" : pre == PRE_LNMOD ? "+lnmod" : "+addsilu"), bytes, 2.0 * M * N * K);
+static void launch_by_cfg(hipStream_t st, const GemmArgs &a, int pre, int cfg) {
   switch (cfg) {
     case 0: launch_cfg<1, 1, 8, 1, 1>(st, a, pre); break;  // 8 waves: most bytes in flight per CU for cold weights
-    // TM >= 2: 4-wave K split measured >= 8-wave (tests/hip/sweep_gemm.hip)
     case 1: launch_cfg<1, 2, 4, 1, 1>(st, a, pre); break;
     case 2: launch_cfg<1, 4, 4, 1, 1>(st, a, pre); break;
     case 3: launch_cfg<2, 4, 1, 2, 2>(st, a, pre); break;
@@ -359,8 +369,94 @@ static void launch_gemm(hipStream_t st, const GemmArgs &a_in, int pre) {
     case 6: launch_cfg<1, 1, 1, 1, 4>(st, a, pre); break;
     case 7: launch_cfg<2, 4, 4, 1, 1>(st, a, pre); break;
     case 8: launch_lds<4, 8>(st, a, pre); break;
-    default: launch_lds<4, 4>(st, a, pre); break;
+    case 9: launch_lds<4, 4>(st, a, pre); break;
+    case 10: launch_cfg<2, 2, 4, 1, 1>(st, a, pre); break;
+    case 11: launch_cfg<1, 1, 4, 1, 1>(st, a, pre); break;
+    case 12: launch_lds<4, 2>(st, a, pre); break;
+    case 13: launch_cfg<1, 2, 1, 2, 2>(st, a, pre); break;
+    case 14: launch_cfg<2, 4, 2, 2, 1>(st, a, pre); break;
+    default: launch_lds<8, 8>(st, a, pre); break;
   }
+}
+
+// Per-engine table of measured tile choices.  `ptts_tune` runs one FlowLM step and one codec frame of a given
+// batch on scratch states with `active` set: every GEMM shape met for the first time is timed with every valid
+// configuration (caches flushed before each timed launch, as in the real step where ~1 GB streams between two
+// uses of a weight) and the fastest is remembered.  Shapes never tuned fall back to pick_cfg.
+typedef std::array<int, 12> TuneKey;
+struct Tuner {
+  std::map<TuneKey, int> table;
+  bool active = false;
+  void *flush = nullptr;
+  size_t flush_bytes = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  std::string log;
+};
+static thread_local Tuner *g_tuner = nullptr;
+static thread_local const float *g_zeros = nullptr;  // both set by the entry points from the engine
+
+static TuneKey tune_key(const GemmArgs &a, int pre) {
+  return TuneKey{a.NT, a.KF, a.CF, a.ntaps, a.MT, a.epi, pre, a.act, a.xstride, a.halo_mode, a.Yraw ? 1 : 0, a.R ? 1 : 0};
+}
+
+// Evicts L2 and the Infinity Cache by READING a large buffer (a write flush would leave dirty lines whose
+// write-back then competes with the timed kernel).
+__global__ void flush_read_kernel(const f32x4 *p, size_t n, float *sink) {
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += p[i];
+  if (s.x + s.y + s.z + s.w == 123.456f) *sink = s.x;  // never true for a zero buffer; keeps the loads alive
+}
+
+static int tune_one(hipStream_t st, const GemmArgs &a, int pre, Tuner &t) {
+  int best = pick_cfg(a);
+  float best_ms = 1e30f, heur_ms = 0.f;
+  const int heur = best;
+  for (int cfg = 0; cfg < kNumCfg; ++cfg) {
+    if (!cfg_valid(cfg, a, pre)) continue;
+    float ms_min = 1e30f;
+    for (int r = 0; r < 4; ++r) {
+      if (t.flush) flush_read_kernel<<<4096, 256, 0, st>>>((const f32x4 *)t.flush, t.flush_bytes / 16, (float *)t.flush);
+      (void)hipEventRecord(t.e0, st);
+      launch_by_cfg(st, a, pre, cfg);
+      (void)hipEventRecord(t.e1, st);
+      if (hipEventSynchronize(t.e1) != hipSuccess) return heur;
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, t.e0, t.e1);
+      ms_min = std::min(ms_min, ms);
+    }
+    if (cfg == heur) heur_ms = ms_min;
+    if (ms_min < best_ms) { best_ms = ms_min; best = cfg; }
+  }
+  if (best_ms > 1e29f) return heur;
+  char line[256];
+  snprintf(line, sizeof line, "%s NT=%d KF=%d taps=%d MT=%d epi=%d pre=%d: %s %.1f us (heuristic %s %.1f us)\n", g_site, a.NT,
+           a.KF, a.ntaps, a.MT, a.epi, pre, kCfgName[best], best_ms * 1e3, kCfgName[heur], heur_ms * 1e3);
+  t.log += line;
+  return best;
+}
+
+static void launch_gemm(hipStream_t st, const GemmArgs &a_in, int pre) {
+  GemmArgs a = a_in;
+  a.zeros = g_zeros;
+  // algorithmic traffic: weights once + input rows once (x taps re-read from cache, not counted) + output
+  const double K = (double)a.KF * 16, N = (double)a.NT * 16, M = (double)a.M;
+  double bytes = 4.0 * (N * K + M * (double)a.CF * 16 + M * N);
+  if (a.epi == EPI_RES || a.epi == EPI_GATE) bytes += 4.0 * M * N;
+  int cfg = -1;
+  if (g_tuner) {
+    const TuneKey key = tune_key(a, pre);
+    auto it = g_tuner->table.find(key);
+    if (it != g_tuner->table.end()) cfg = it->second;
+    else if (g_tuner->active) cfg = g_tuner->table[key] = tune_one(st, a, pre, *g_tuner);
+  }
+  if (cfg < 0 || !cfg_valid(cfg, a, pre)) cfg = pick_cfg(a);
+  ProfScope ps(st, std::string(kCfgName[cfg]) + (pre == PRE_NONE ? "" : pre == PRE_LNFOLD ? "+ln" : pre == PRE_LNMOD ? "+lnmod" : "+addsilu"), bytes, 2.0 * M * N * K);
+  launch_by_cfg(st, a, pre, cfg);
+}
+
+static void bind_engine(ptts_engine *e) {
+  g_zeros = e->zeros;
+  g_tuner = e->tuner;
 }
 
 static GemmArgs mk_gemm(const Lin &L, const float *X, int XF, int MT, int M) {
@@ -489,6 +585,7 @@ extern "C" int ptts_create(const ptts_config *cfg, const ptts_tensor *tensors, i
   ptts_engine *e = new ptts_engine();
   e->cfg = *cfg;
   e->device = device;
+  e->tuner = new Tuner();
   HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   g_alloc_stream = e->stream;
   HIPCHK(hipEventCreate(&e->ev0));
@@ -614,6 +711,8 @@ extern "C" void ptts_destroy(ptts_engine *e) {
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   if (e->stream) hipStreamDestroy(e->stream);
+  if (g_tuner == e->tuner) g_tuner = nullptr;
+  delete e->tuner;
   delete e;
 }
 
@@ -622,7 +721,7 @@ static hipStream_t S(ptts_engine *e, void *stream) { return stream ? (hipStream_
 // time-embedding constant for a given LSD schedule (reference mlp.py:203-206): computed once on device
 static int prepare_lsd(ptts_engine *e, int steps) {
   if (e->tcomb.count(steps)) return 0;
-  g_zeros = e->zeros;
+  bind_engine(e);
   if (steps < 1 || steps > 64) return fail(-1, "lsd_decode_steps out of range");
   const int FD = e->cfg.flow_dim;
   float *tab;
@@ -869,7 +968,7 @@ extern "C" int64_t ptts_profile_stop(ptts_engine *e, char *h_out, int64_t capaci
 
 static void lm_layers(hipStream_t st, ptts_engine *e, ptts_lm_state *s, Scratch &sc, int M, int Tq) {
   const ptts_config &c = e->cfg;
-  g_zeros = e->zeros;
+  bind_engine(e);
   SITE("lm.rope");
   {
     ProfScope ps(st, "rope_table", 256.0 * M, 0);
@@ -920,7 +1019,7 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
                            const float *d_noise, int lsd_steps, float eos_thr, float *d_latent_out,
                            float *d_eos_logit, uint8_t *d_is_eos) {
   const ptts_config &c = e->cfg;
-  g_zeros = e->zeros;
+  bind_engine(e);
   const int B = s->B, MT = s->MT, D = c.d_model, FD = c.flow_dim, DF = D / 16, FDF = FD / 16, LF = c.ldim / 16;
   Scratch &sc = s->dec;
   const float *tcomb = e->tcomb[lsd_steps];
@@ -1083,7 +1182,7 @@ extern "C" int ptts_mimi_state_reset(ptts_mimi_state *s, void *stream) {
 
 static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, const float *d_latent, float *d_pcm) {
   const ptts_config &c = e->cfg;
-  g_zeros = e->zeros;
+  bind_engine(e);
   const int B = s->B, C = c.m_dim, CF = C / 16, LF = c.ldim / 16, st16 = c.upsample_stride;
   SITE("mimi.prep");
   {
@@ -1183,6 +1282,50 @@ extern "C" int ptts_mimi_decode(ptts_engine *e, ptts_mimi_state *s, const float 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Tile autotuning for one batch size (see Tuner).  Runs on scratch states; the caller's states are untouched.
+extern "C" int ptts_tune(ptts_engine *e, int32_t B, void *stream) {
+  if (!e || B < 1) return fail(-1, "bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  hipStream_t st = S(e, stream);
+  Tuner &t = *e->tuner;
+  ptts_lm_state *ls = nullptr;
+  ptts_mimi_state *ms = nullptr;
+  int rc = ptts_lm_state_create(e, B, 32, &ls);
+  if (rc == 0) rc = ptts_mimi_state_create(e, B, &ms);
+  t.flush_bytes = (size_t)320 << 20;  // > Infinity Cache (256 MiB)
+  if (rc == 0) {
+    if (hipMalloc(&t.flush, t.flush_bytes) != hipSuccess) { t.flush = nullptr; (void)hipGetLastError(); }  // tune warm if memory is short
+    else (void)hipMemsetAsync(t.flush, 0, t.flush_bytes, st);
+  }
+  if (rc == 0 && (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess)) rc = fail(-2, "hipEventCreate");
+  if (rc == 0) {
+    HIPCHK(hipStreamSynchronize(e->stream));  // state zero-fills
+    const bool prof = g_prof_on;
+    g_prof_on = false;
+    t.active = true;
+    rc = ptts_lm_decode_step(e, ls, nullptr, nullptr, 1, 1e30f, nullptr, nullptr, nullptr, st);
+    if (rc == 0) rc = ptts_mimi_decode(e, ms, ls->lat, nullptr, st);
+    t.active = false;
+    g_prof_on = prof;
+    if (hipStreamSynchronize(st) != hipSuccess && rc == 0) rc = fail(-2, "tune: stream error");
+  }
+  if (t.e0) hipEventDestroy(t.e0);
+  if (t.e1) hipEventDestroy(t.e1);
+  t.e0 = t.e1 = nullptr;
+  if (t.flush) hipFree(t.flush);
+  t.flush = nullptr;
+  if (ms) ptts_mimi_state_destroy(ms);
+  if (ls) ptts_lm_state_destroy(ls);
+  return rc;
+}
+
+extern "C" const char *ptts_tune_log(ptts_engine *e) { return e ? e->tuner->log.c_str() : ""; }
+
+extern "C" void ptts_tune_clear(ptts_engine *e) {
+  if (e) { e->tuner->table.clear(); e->tuner->log.clear(); }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Voice-prompt encode path (one-off per voice): MimiModel.encode_to_latent + speaker projection
 // (reference mimi.py:96-119, tts_model.py:379-388).  Whole-signal causal convs = the same implicit GEMMs with
 // zero / replicate left padding and an input stride.
@@ -1193,7 +1336,7 @@ extern "C" int ptts_encode_voice(ptts_engine *e, const float *d_audio, int64_t n
   HIPCHK(hipSetDevice(e->device));
   const ptts_config &c = e->cfg;
   hipStream_t st = S(e, stream);
-  g_zeros = e->zeros;
+  bind_engine(e);
   g_alloc_stream = st;
   const int hop = c.ratios[0] * c.ratios[1] * c.ratios[2];
   const long fs = (long)hop * c.upsample_stride;  // 1920

@@ -12,6 +12,7 @@ Mirrors the reference's internal seam:
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -133,6 +134,7 @@ class Engine:
         self.lib = _lib.load()
         self.handle = None
         self._states = weakref.WeakSet()
+        self._tuned = set()
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -201,6 +203,16 @@ class Engine:
         ms = C.c_float()
         _lib.check(self.lib.ptts_timer_stop_ms(self.handle, self._sp, C.byref(ms)))
         return ms.value
+
+    def tune(self, batch: int, force: bool = False) -> str:
+        """Measure the tile configuration of every GEMM on the step path for this batch size (once per
+        engine and batch; `PTTS_NO_TUNE=1` keeps the static heuristic).  Returns the tuner's log."""
+        if os.environ.get("PTTS_NO_TUNE") == "1" or (batch in self._tuned and not force):
+            return ""
+        self._pre()
+        _lib.check(self.lib.ptts_tune(self.handle, int(batch), self._sp))
+        self._tuned.add(batch)
+        return (self.lib.ptts_tune_log(self.handle) or b"").decode()
 
     def profile_start(self):
         _lib.check(self.lib.ptts_profile_start(self.handle))
@@ -382,6 +394,7 @@ class StepPipeline:
         self.s2 = torch.cuda.Stream(device=dev)
         eng.sync()
         torch.cuda.synchronize(dev)
+        eng.tune(B)  # before capture: graphs freeze the tile choices
         lib, H = eng.lib, eng.handle
         self.g_first = [eng.capture_lm_step(lm_state, noise, lsd_steps, eos_threshold, self.lat[p], self.logit[p],
                                             self.flag[p]) for p in range(2)]

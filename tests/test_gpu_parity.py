@@ -230,6 +230,7 @@ def test_pipelined_graph_matches_eager():
 
     eng = get_engine("tiny")
     B, Tp, ns = 3, 23, 9
+    eng.tune(B)  # StepPipeline tunes the tiles for its batch: the eager reference must use the same ones
     rng = np.random.default_rng(11)
     emb = dev((rng.standard_normal((B, Tp, eng.D)) * 0.5).astype(np.float32))
     st, ms = eng.new_lm_state(B, Tp + ns), eng.new_mimi_state(B)
@@ -295,3 +296,37 @@ def test_voice_encode_long_audio_vs_oracle():
     torch.cuda.synchronize()
     assert cond.shape == ref.shape == (54, eng.D)
     assert _maxerr(cond.cpu().numpy(), ref) < ATOL
+
+
+@pytest.mark.parametrize("cfg_name,B", [("tiny", 3), ("en100m", 2), ("en100m", 20)])
+def test_tuned_tiles_match_static_choice(cfg_name, B):
+    """`Engine.tune` only changes which tile configuration computes each GEMM: latents, EOS logits and PCM of a
+    few steps must agree with the untuned run to fp32 summation-order accuracy, and every tuned shape must be
+    reported in the log."""
+    eng = get_engine(cfg_name)
+    rng = np.random.default_rng(5)
+    Tp, ns = 19, 4
+    emb = dev((rng.standard_normal((B, Tp, eng.D)) * 0.5).astype(np.float32))
+
+    def run():
+        st, ms = eng.new_lm_state(B, Tp + ns), eng.new_mimi_state(B)
+        eng.lm_prefill(st, emb)
+        out = []
+        for _ in range(ns):
+            o, logit, _ = eng.lm_decode_step(st, None, None, 1, -4.0)
+            pcm = eng.mimi_decode(ms, o)
+            torch.cuda.synchronize()
+            out.append((o.cpu().numpy().copy(), logit.cpu().numpy().copy(), pcm.cpu().numpy().copy()))
+        st.close(); ms.close()
+        return out
+
+    eng.lib.ptts_tune_clear(eng.handle)
+    eng._tuned.clear()
+    base = run()
+    log = eng.tune(B, force=True)
+    assert "lm.qkv" in log and "seanet.convtr1" in log and "flow.adaln" in log
+    tuned = run()
+    for (a, la, pa), (b, lb, pb) in zip(base, tuned):
+        assert np.allclose(a, b, atol=2e-5, rtol=1e-5)
+        assert np.allclose(la, lb, atol=5e-5, rtol=1e-5)
+        assert np.allclose(pa, pb, atol=2e-5, rtol=1e-5)
