@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--quantize", action="store_true",
+                    help="BASELINE config #5: int8 weights for the FlowLM attention + FFN layers (not the headline: "
+                         "the default run is the fp32 path whose parity is pinned)")
     ap.add_argument("--cpu-steps", type=int, default=8)
     return ap.parse_args()
 
@@ -218,7 +221,7 @@ def main():
 
     cfg = named_config(args.config)
     W = generate_state_dict(cfg, 0)
-    eng = Engine(cfg, W, dev)
+    eng = Engine(cfg, W, dev, quantize_groups={"attention", "ffn"} if args.quantize else None)
     job = Job(eng, args.batch, args, seed=rank)
 
     def barrier():
@@ -257,7 +260,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "int8 weights (FlowLM attention+ffn), f32 activations/accumulate" if args.quantize else "f32",
             "data": "synthetic (seeded weights, voice KV, token ids; fixed-length utterances, EOS stop disabled)",
             "config": {
                 "workload": f"{args.config}: batch {args.batch} concurrent utterances/GPU, voice KV {args.voice_len} + "

@@ -52,6 +52,15 @@ const char *ptts_last_error(void);
  * for the decode-side modules.  The caller may free the source tensors afterwards. */
 int ptts_create(const ptts_config *cfg, const ptts_tensor *tensors, int32_t n_tensors, int32_t device,
                 ptts_engine **out);
+/* Same, with int8 weights for layer groups of the FlowLM transformer: replaces
+ * quantization.apply_dynamic_int8(flow_lm, groups) (quantization.py:60-128; load_model(quantize=True) uses
+ * {"attention", "ffn"}, tts_model.py:312-315).  The reference quantises activations dynamically as well (torch.ao /
+ * torchao CPU kernels); here the weights are int8 per output channel (symmetric) and activations and accumulation
+ * stay fp32, so the result is closer to the fp32 model than the reference's int8 path.  flags = 0 == ptts_create. */
+#define PTTS_QUANT_ATTENTION 1 /* self_attn.in_proj, self_attn.out_proj */
+#define PTTS_QUANT_FFN 2       /* linear1, linear2 */
+int ptts_create_ex(const ptts_config *cfg, const ptts_tensor *tensors, int32_t n_tensors, int32_t device,
+                   int32_t quant_flags, ptts_engine **out);
 void ptts_destroy(ptts_engine *e);
 
 /* ---- FlowLM state: init_states(flow_lm, B, T) (stateful_module.py:7-16, transformer.py:46-57) */

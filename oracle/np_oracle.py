@@ -496,3 +496,38 @@ def autoregressive_generation(lm, state, max_gen_len, frames_after_eos, noise=No
             break
         lat.append(x.copy())
     return np.stack(lat) if lat else np.zeros((0, B, lm.ldim), F32), np.stack(logits), eos_step
+
+
+# --------------------------------------------------------------------------------------------------
+# int8 weight path (BASELINE config #5).  The reference quantises the FlowLM transformer's Linear layers with
+# torch.ao / torchao *dynamic* int8 (quantization.py:60-128: groups "attention" = self_attn.in_proj/out_proj,
+# "ffn" = linear1/linear2; load_model(quantize=True) uses both, tts_model.py:312-315).  Those CPU kernels
+# (FBGEMM / QNNPACK / torchao) are third-party code outside /root/reference and also quantise the activations;
+# the build's GPU path is weight-only: int8 per output channel, symmetric, fp32 activations and accumulation.
+# This function restates THAT scheme (parity unpinned against the reference's int8 arithmetic; the GPU tests
+# report SNR against the fp32 model next to it, the reference's own quality metric,
+# scripts/evaluate_quantization.py:215-228).
+QUANT_GROUP_SUFFIXES = {
+    "attention": ("self_attn.in_proj.weight", "self_attn.out_proj.weight"),
+    "ffn": ("linear1.weight", "linear2.weight"),
+}
+
+
+def quantize_dequantize_int8(w):
+    """per-row symmetric int8: scale = max|w| / 127, q = rint(w / scale) clipped to [-127, 127]; returns q * scale"""
+    w = np.asarray(w, np.float32)
+    mx = np.abs(w).max(axis=1, keepdims=True).astype(np.float32)
+    scale = np.where(mx > 0, mx / np.float32(127.0), np.float32(1.0)).astype(np.float32)
+    q = np.clip(np.rint(w / scale), -127, 127).astype(np.float32)
+    return (q * scale).astype(np.float32)
+
+
+def quantized_weights(W, groups=("attention", "ffn")):
+    """copy of the weight dict with the FlowLM transformer's Linear weights of `groups` replaced by their
+    int8-dequantised values; everything else (flow net, Mimi, embeddings, norms) stays fp32"""
+    out = dict(W)
+    for g in groups:
+        for name in W:
+            if name.startswith("flow_lm.transformer.layers.") and name.endswith(QUANT_GROUP_SUFFIXES[g]):
+                out[name] = quantize_dequantize_int8(W[name])
+    return out

@@ -39,6 +39,7 @@ PROTOTYPES = {
     "ptts_abi_version": (C.c_int, []),
     "ptts_last_error": (C.c_char_p, []),
     "ptts_create": (C.c_int, [C.POINTER(PttsConfig), C.POINTER(PttsTensor), C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "ptts_create_ex": (C.c_int, [C.POINTER(PttsConfig), C.POINTER(PttsTensor), C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
     "ptts_destroy": (None, [_P]),
     "ptts_lm_state_create": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(_P)]),
     "ptts_lm_state_destroy": (None, [_P]),

@@ -60,7 +60,10 @@ struct Lin {  // one packed weight matrix
   int N = 0, NT = 0, C = 0, CF = 0, ntaps = 1, KF = 0;
   int cout = 0, stride = 0;  // transposed-conv view
   float *ln_s = nullptr, *ln_c = nullptr;  // LayerNorm folded into this matrix (PRE_LNFOLD)
-  size_t bytes() const { return (size_t)NT * KF * 1024; }
+  // int8 weight-only variant (PTTS_QUANT_*): wq replaces w; ln_g = the LayerNorm gain applied to x on load
+  uint8_t *wq = nullptr;
+  float *wscale = nullptr, *ln_g = nullptr;
+  size_t bytes() const { return wq ? (size_t)NT * KF * 256 + (size_t)NT * 64 : (size_t)NT * KF * 1024; }
 };
 
 struct TrLayer {
@@ -100,6 +103,7 @@ struct ptts_engine {
   float *zeros = nullptr;
   int64_t lm_bytes = 0, mimi_bytes = 0;
   struct Tuner *tuner = nullptr;
+  int quant_flags = 0;
 };
 
 struct Scratch {
@@ -202,8 +206,10 @@ struct PackPart { std::string w, b; int N; };
 // packs one or several [N_i][C][ntaps] matrices (stacked along N) into one Lin
 static int pack_lin(ptts_engine *e, Lin *L, const std::vector<PackPart> &parts, int C, int ntaps, int mode = 0,
                     int cout = 0, int stride = 0, const std::string &ln_w = "", const std::string &ln_b = "",
-                    int creal = 0) {
+                    int creal = 0, bool q8 = false) {
   if (C % 16) return fail(-4, "channel count must be a multiple of 16: " + parts[0].w);
+  if (q8 && (parts.size() != 1 || mode != 0 || ntaps != 1 || (C / 16) % 4))
+    return fail(-4, "int8 weights need a single Linear matrix with in_features % 64 == 0: " + parts[0].w);
   int ntot = 0;
   for (auto &p : parts) ntot += cdiv(p.N, 16);
   L->NT = ntot;
@@ -238,8 +244,8 @@ static int pack_lin(ptts_engine *e, Lin *L, const std::vector<PackPart> &parts, 
     int nt = cdiv(p.N, 16);
     long total = (long)nt * L->KF * 256;
     pack_weight_kernel<<<cdiv(total, 256), 256, 0, e->stream>>>(t->d_data, L->w, p.N, C, ntaps, mode, cout, stride,
-                                                                nt_off, L->KF, total, gam, creal > 0 ? creal : C);
-    if (gam) {
+                                                                nt_off, L->KF, total, q8 ? nullptr : gam, creal > 0 ? creal : C);
+    if (gam && !q8) {
       const float *bsrc = nullptr;
       if (!p.b.empty()) {
         const ptts_tensor *tb2 = find_tensor(e, p.b, p.N, &err);
@@ -260,11 +266,31 @@ static int pack_lin(ptts_engine *e, Lin *L, const std::vector<PackPart> &parts, 
     nt_off += nt;
     L->N += p.N;
   }
+  if (q8) {
+    int err = 0;
+    const float *bsrc = nullptr;
+    if (gam && !parts[0].b.empty()) {
+      const ptts_tensor *tb2 = find_tensor(e, parts[0].b, parts[0].N, &err);
+      if (!tb2) return err;
+      bsrc = tb2->d_data;
+    }
+    CHK(dalloc(e, (void **)&L->wq, (size_t)L->NT * L->KF * 256));
+    CHK(dallocT(e, &L->wscale, (size_t)L->NT * 16));
+    if (gam) CHK(copy_vec(e, ln_w, C, &L->ln_g));
+    quantize_packed_kernel<<<L->NT, 256, 0, e->stream>>>(L->w, L->wq, L->wscale, L->KF, gam, bet, bsrc, L->N, L->ln_s, L->ln_c);
+    HIPCHK(hipGetLastError());
+    // the fp32 image is only the quantiser's input
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->allocs.erase(std::remove(e->allocs.begin(), e->allocs.end(), (void *)L->w), e->allocs.end());
+    HIPCHK(hipFree(L->w));
+    L->w = nullptr;
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-static int pack_tr_layer(ptts_engine *e, TrLayer *T, const std::string &p, int d, int ff, bool ls) {
+static int pack_tr_layer(ptts_engine *e, TrLayer *T, const std::string &p, int d, int ff, bool ls, int quant = 0) {
+  const bool qa = quant & PTTS_QUANT_ATTENTION, qf = quant & PTTS_QUANT_FFN;
   CHK(copy_vec(e, p + ".norm1.weight", d, &T->ln1_w));
   CHK(copy_vec(e, p + ".norm1.bias", d, &T->ln1_b));
   CHK(copy_vec(e, p + ".norm2.weight", d, &T->ln2_w));
@@ -273,10 +299,10 @@ static int pack_tr_layer(ptts_engine *e, TrLayer *T, const std::string &p, int d
     CHK(copy_vec(e, p + ".layer_scale_1.scale", d, &T->ls1));
     CHK(copy_vec(e, p + ".layer_scale_2.scale", d, &T->ls2));
   }
-  CHK(pack_lin(e, &T->qkv, {{p + ".self_attn.in_proj.weight", "", 3 * d}}, d, 1, 0, 0, 0, p + ".norm1.weight", p + ".norm1.bias"));
-  CHK(pack_lin(e, &T->out, {{p + ".self_attn.out_proj.weight", "", d}}, d, 1));
-  CHK(pack_lin(e, &T->ff1, {{p + ".linear1.weight", "", ff}}, d, 1, 0, 0, 0, p + ".norm2.weight", p + ".norm2.bias"));
-  CHK(pack_lin(e, &T->ff2, {{p + ".linear2.weight", "", d}}, ff, 1));
+  CHK(pack_lin(e, &T->qkv, {{p + ".self_attn.in_proj.weight", "", 3 * d}}, d, 1, 0, 0, 0, p + ".norm1.weight", p + ".norm1.bias", 0, qa));
+  CHK(pack_lin(e, &T->out, {{p + ".self_attn.out_proj.weight", "", d}}, d, 1, 0, 0, 0, "", "", 0, qa));
+  CHK(pack_lin(e, &T->ff1, {{p + ".linear1.weight", "", ff}}, d, 1, 0, 0, 0, p + ".norm2.weight", p + ".norm2.bias", 0, qf));
+  CHK(pack_lin(e, &T->ff2, {{p + ".linear2.weight", "", d}}, ff, 1, 0, 0, 0, "", "", 0, qf));
   return 0;
 }
 
@@ -293,6 +319,15 @@ static int make_freq(ptts_engine *e, float **out, float max_period) {
 
 // ------------------------------------------------------------------------------------------------
 // GEMM dispatch
+// int8-weight variants exist for these tiles and for plain / LN-folded operands only
+template <int TN, int TM, int WK, int WN, int WM>
+static void launch_cfg_q8(hipStream_t st, const GemmArgs &a, int pre) {
+  dim3 grid(cdiv(a.NT, TN * WN), cdiv(a.MT, TM * WM));
+  dim3 block(64 * WK * WN * WM);
+  if (pre == PRE_LNFOLD) gemm_kernel<TN, TM, WK, WN, WM, PRE_LNFOLD, true><<<grid, block, 0, st>>>(a);
+  else gemm_kernel<TN, TM, WK, WN, WM, PRE_NONE, true><<<grid, block, 0, st>>>(a);
+}
+
 template <int TN, int TM, int WK, int WN, int WM>
 static void launch_cfg(hipStream_t st, const GemmArgs &a, int pre) {
   dim3 grid(cdiv(a.NT, TN * WN), cdiv(a.MT, TM * WM));
@@ -345,8 +380,14 @@ static const int kCfgShape[kNumCfg][5] = {{1, 1, 8, 1, 1}, {1, 2, 4, 1, 1}, {1, 
                                           {2, 2, 4, 1, 1}, {1, 1, 4, 1, 1}, {2, 4, 0, 0, 0}, {1, 2, 1, 2, 2}, {2, 4, 2, 2, 1},
                                           {8, 8, 0, 0, 0}};
 
+static bool q8_cfg(int cfg) { return cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 7 || cfg == 10 || cfg == 11; }
+
 static bool cfg_valid(int cfg, const GemmArgs &a, int pre) {
   const int *s = kCfgShape[cfg];
+  if (a.Wq) {  // whole groups of four k-fragments per wave
+    if (!q8_cfg(cfg) || (pre != PRE_NONE && pre != PRE_LNFOLD)) return false;
+    if (a.KF % (4 * s[2])) return false;
+  }
   if (s[2] == 0) {  // LDS-staged: two k-fragments per stage, plain or LN-folded operand only
     if (a.KF % 2 || (pre != PRE_NONE && pre != PRE_LNFOLD)) return false;
     return a.MT >= s[1] && 2 * a.NT >= s[0];
@@ -359,6 +400,18 @@ static bool cfg_valid(int cfg, const GemmArgs &a, int pre) {
 }
 
 static void launch_by_cfg(hipStream_t st, const GemmArgs &a, int pre, int cfg) {
+  if (a.Wq) {
+    switch (cfg) {
+      case 0: launch_cfg_q8<1, 1, 8, 1, 1>(st, a, pre); break;
+      case 1: launch_cfg_q8<1, 2, 4, 1, 1>(st, a, pre); break;
+      case 2: launch_cfg_q8<1, 4, 4, 1, 1>(st, a, pre); break;
+      case 7: launch_cfg_q8<2, 4, 4, 1, 1>(st, a, pre); break;
+      case 10: launch_cfg_q8<2, 2, 4, 1, 1>(st, a, pre); break;
+      case 11: launch_cfg_q8<1, 1, 4, 1, 1>(st, a, pre); break;
+      default: launch_cfg_q8<2, 4, 1, 2, 2>(st, a, pre); break;  // 3: no K split, any KF % 4 == 0
+    }
+    return;
+  }
   switch (cfg) {
     case 0: launch_cfg<1, 1, 8, 1, 1>(st, a, pre); break;  // 8 waves: most bytes in flight per CU for cold weights
     case 1: launch_cfg<1, 2, 4, 1, 1>(st, a, pre); break;
@@ -450,6 +503,8 @@ static void launch_gemm(hipStream_t st, const GemmArgs &a_in, int pre) {
     else if (g_tuner->active) cfg = g_tuner->table[key] = tune_one(st, a, pre, *g_tuner);
   }
   if (cfg < 0 || !cfg_valid(cfg, a, pre)) cfg = pick_cfg(a);
+  if (a.Wq && !cfg_valid(cfg, a, pre)) cfg = 3;
+  if (a.Wq) bytes -= 3.0 * N * K;  // one byte per weight
   ProfScope ps(st, std::string(kCfgName[cfg]) + (pre == PRE_NONE ? "" : pre == PRE_LNFOLD ? "+ln" : pre == PRE_LNMOD ? "+lnmod" : "+addsilu"), bytes, 2.0 * M * N * K);
   launch_by_cfg(st, a, pre, cfg);
 }
@@ -463,6 +518,9 @@ static GemmArgs mk_gemm(const Lin &L, const float *X, int XF, int MT, int M) {
   GemmArgs a;
   memset(&a, 0, sizeof(a));
   a.W = L.w;
+  a.Wq = L.wq;
+  a.wscale = L.wscale;
+  a.ln_g = L.ln_g;
   a.bias = L.bias;
   a.ln_s = L.ln_s;
   a.ln_c = L.ln_c;
@@ -579,13 +637,20 @@ static int seanet_check(const ptts_config &c) {
 
 extern "C" int ptts_create(const ptts_config *cfg, const ptts_tensor *tensors, int32_t n, int32_t device,
                            ptts_engine **out) {
+  return ptts_create_ex(cfg, tensors, n, device, 0, out);
+}
+
+extern "C" int ptts_create_ex(const ptts_config *cfg, const ptts_tensor *tensors, int32_t n, int32_t device,
+                              int32_t quant_flags, ptts_engine **out) {
   if (!cfg || !tensors || !out) return fail(-1, "null argument");
+  if (quant_flags & ~(PTTS_QUANT_ATTENTION | PTTS_QUANT_FFN)) return fail(-1, "unknown quantisation group");
   CHK(seanet_check(*cfg));
   HIPCHK(hipSetDevice(device));
   ptts_engine *e = new ptts_engine();
   e->cfg = *cfg;
   e->device = device;
   e->tuner = new Tuner();
+  e->quant_flags = quant_flags;
   HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   g_alloc_stream = e->stream;
   HIPCHK(hipEventCreate(&e->ev0));
@@ -599,7 +664,7 @@ extern "C" int ptts_create(const ptts_config *cfg, const ptts_tensor *tensors, i
   CHK(pack_lin(e, &e->in_linear, {{p + "input_linear.weight", "", D}}, c.ldim, 1));
   e->lm.resize(c.num_layers);
   for (int l = 0; l < c.num_layers; ++l)
-    CHK(pack_tr_layer(e, &e->lm[l], p + "transformer.layers." + std::to_string(l), D, c.ff_dim, false));
+    CHK(pack_tr_layer(e, &e->lm[l], p + "transformer.layers." + std::to_string(l), D, c.ff_dim, false, e->quant_flags));
   CHK(copy_vec(e, p + "out_norm.weight", D, &e->outnorm_w));
   CHK(copy_vec(e, p + "out_norm.bias", D, &e->outnorm_b));
   std::string f = p + "flow_net.";

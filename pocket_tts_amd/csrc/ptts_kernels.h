@@ -20,6 +20,7 @@
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // Ablation switches for tests/hip/bench_gemm.hip only (timing builds; results are wrong when set):
 // 1 = no X loads, 2 = no W loads, 4 = no MFMA.  Always 0 in the library.
@@ -54,6 +55,11 @@ __device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
 struct GemmArgs {
   // weights, packed [NT][KF][64][4]; bias padded to NT*16
   const float *W, *bias;
+  // int8 weight-only variant (Q8 kernels): biased bytes (q + 128) packed [NT][KF/4][64][16] so that one 16-byte load
+  // per lane carries the lane's operands of FOUR consecutive k-fragments; y[n] = wscale[n] * sum_k q[n][k] x[k]
+  const uint8_t *Wq;
+  const float *wscale;
+  const float *ln_g;  // Q8 + PRE_LNFOLD: the LayerNorm gain stays out of the quantised matrix and scales x on load
   int NT, KF, CF, ntaps;
   // input FM view; double-buffered by frame parity when Xdstride != 0
   const float *X;
@@ -220,7 +226,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 acc, int 
 }
 
 // TN x TM 16x16 tiles per wave; WK waves split K (LDS-reduced), WN x WM waves tile N x M.
-template <int TN, int TM, int WK, int WN, int WM, int PRE>
+template <int TN, int TM, int WK, int WN, int WM, int PRE, bool Q8 = false>
 __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
   constexpr int NW = WK * WN * WM;
   const int lane = threadIdx.x & 63;
@@ -249,10 +255,12 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
       for (int q = 0; q < NACC; ++q) acc[i][j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const float *wb[TN];
+  const uint8_t *wqb[TN];
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
     int nt = nt0 + i < a.NT ? nt0 + i : a.NT - 1;
     wb[i] = a.W + (size_t)nt * a.KF * 256 + lane * 4;
+    wqb[i] = Q8 ? a.Wq + (size_t)nt * a.KF * 256 + lane * 16 : nullptr;
   }
   int mtc[TM], tin[TM], bT[TM];
 #pragma unroll
@@ -304,7 +312,8 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
   // MFMAs of chunk c, into a second register set, so the matrix pipe works while the next operands fly.
   // decode (K-split) tiles: as many fragments per round as the register file allows, so that a wave needs
   // few serialized HBM round trips for its cold weight stream
-  constexpr int U = (TN * TM == 1) ? 8 : (TN * TM == 2 && WK > 1) ? 8 : (TN * TM <= 4 && WK > 1) ? 4 : 2;
+  constexpr int U0 = (TN * TM == 1) ? 8 : (TN * TM == 2 && WK > 1) ? 8 : (TN * TM <= 4 && WK > 1) ? 4 : 2;
+  constexpr int U = (Q8 && U0 < 4) ? 4 : U0;  // int8 weights arrive four k-fragments per load
   auto load_chunk = [&](auto uc, int kf, f32x4 (*w)[TN], f32x4 (*x)[TM]) {
     constexpr int UU = decltype(uc)::value;
 #pragma unroll
@@ -313,7 +322,13 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
       for (int i = 0; i < TN; ++i) {
         // weights are read exactly once by the K-split (decode) configuration: stream them non-temporally
         if constexpr (PTTS_ABLATE & 2) w[u][i] = (f32x4){1.f, 2.f, 3.f, (float)lane};
-        else if constexpr (WK > 1) w[u][i] = __builtin_nontemporal_load((const f32x4 *)(wb[i] + (size_t)(kf + u) * 256));
+        else if constexpr (Q8) {
+          // raw bytes of fragments kf+u .. kf+u+3, parked in slot u/4 until compute_chunk converts them
+          if (u % 4 == 0) {
+            const i32x4 raw = __builtin_nontemporal_load((const i32x4 *)(wqb[i] + (size_t)(kf + u) * 256));
+            w[u / 4][i] = __builtin_bit_cast(f32x4, raw);
+          }
+        } else if constexpr (WK > 1) w[u][i] = __builtin_nontemporal_load((const f32x4 *)(wb[i] + (size_t)(kf + u) * 256));
         else w[u][i] = *(const f32x4 *)(wb[i] + (size_t)(kf + u) * 256);
       }
       if constexpr (PTTS_ABLATE & 1) {
@@ -364,6 +379,21 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
           sx[j] += (v.x + v.y) + (v.z + v.w);
           sxx[j] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
+        if constexpr (Q8) {
+          const f32x4 g4 = *(const f32x4 *)(a.ln_g + 16 * (kf + u) + 4 * (lane >> 4));
+#pragma unroll
+          for (int j = 0; j < TM; ++j) x[u][j] *= g4;
+        }
+      }
+      f32x4 wv[TN];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        if constexpr (Q8) {
+          const unsigned word = (unsigned)__builtin_bit_cast(i32x4, w[u / 4][i])[u % 4];
+          wv[i] = (f32x4){(float)(word & 0xffu), (float)((word >> 8) & 0xffu), (float)((word >> 16) & 0xffu), (float)(word >> 24)} - 128.0f;
+        } else {
+          wv[i] = w[u][i];
+        }
       }
       // k-step major: back-to-back MFMAs hit DIFFERENT accumulators, so none waits out the 40-cycle
       // dependent-accumulator latency of v_mfma_f32_16x16x4_f32 (issue interval 32 cycles)
@@ -373,10 +403,10 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
         for (int i = 0; i < TN; ++i)
 #pragma unroll
           for (int j = 0; j < TM; ++j) {
-            if constexpr (PTTS_ABLATE & 4) acc[i][j][cidx % NACC][cidx] += w[u][i][cidx] + x[u][j][cidx];
+            if constexpr (PTTS_ABLATE & 4) acc[i][j][cidx % NACC][cidx] += wv[i][cidx] + x[u][j][cidx];
             else
               acc[i][j][cidx % NACC] =
-                  __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][i][cidx], x[u][j][cidx], acc[i][j][cidx % NACC], 0, 0, 0);
+                  __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i][cidx], x[u][j][cidx], acc[i][j][cidx % NACC], 0, 0, 0);
           }
     }
   };
@@ -409,6 +439,14 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
       kf += U;
     }
   }
+  if constexpr (Q8) {
+    const std::integral_constant<int, 4> c4{};  // host guarantees (k1 - k0) % 4 == 0
+    for (; kf < k1; kf += 4) {
+      f32x4 w4[4][TN], x4[4][TM];
+      load_chunk(c4, kf, w4, x4);
+      compute_chunk(c4, kf, w4, x4);
+    }
+  }
   for (; kf < k1; ++kf) {
     f32x4 w1[1][TN], x1[1][TM];
     load_chunk(c1, kf, w1, x1);
@@ -433,6 +471,7 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
     }
   }
   auto ln_fix = [&](f32x4 v, int nt, int j) {
+    if constexpr (Q8) v *= *(const f32x4 *)(a.wscale + 16 * nt + 4 * (lane >> 4));
     if constexpr (PRE == PRE_LNFOLD) {
       const int n0 = 16 * nt + 4 * (lane >> 4);
       const f32x4 s4 = *(const f32x4 *)(a.ln_s + n0), c4 = *(const f32x4 *)(a.ln_c + n0);
@@ -690,6 +729,63 @@ __global__ void fold_ln_kernel(const float *W, const float *g, const float *b, c
   if (lane == 0) {
     s_out[n_off + n] = s;
     c_out[n_off + n] = c + (bias ? bias[n] : 0.f);
+  }
+}
+
+// int8 weight-only quantisation of one packed Linear matrix (load time).  One workgroup per 16-row n-tile:
+// per output row, scale = max|w| / 127 (symmetric, per channel), q = rint(w / scale) in [-127, 127], stored as the
+// biased byte q + 128 in the Q8 layout dst[nt][kf/4][lane][4 * (kf % 4) + j4].  For a matrix that follows a
+// LayerNorm (gam/bet non-null) the fold vectors are built from the DEQUANTISED weights:
+//   ln_s[n] = sum_k Wdq[n][k] gam[k],  ln_c[n] = sum_k Wdq[n][k] bet[k] + bias[n]
+// so the result equals LayerNorm followed by a Linear whose weight is Wdq, which is what the oracle computes.
+// (The reference quantises the same Linear layers with torch.ao / torchao dynamic int8, quantization.py:60-128;
+// this build keeps activations in fp32: weight-only, per channel.)
+__global__ __launch_bounds__(256) void quantize_packed_kernel(const float *src, uint8_t *dst, float *wscale, int KF,
+                                                              const float *gam, const float *bet, const float *bias,
+                                                              int N, float *ln_s, float *ln_c) {
+  __shared__ int smax[16];
+  __shared__ float ps[256], pc[256];
+  const int nt = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid >> 2, j4 = tid & 3, row = lane & 15;
+  if (tid < 16) smax[tid] = 0;
+  __syncthreads();
+  const float *s = src + (size_t)nt * KF * 256;
+  float m = 0.f;
+  for (int kf = 0; kf < KF; ++kf) m = fmaxf(m, fabsf(s[(size_t)kf * 256 + tid]));
+  atomicMax(&smax[row], __float_as_int(m));  // non-negative floats order like their bit patterns
+  __syncthreads();
+  const float mx = __int_as_float(smax[row]);
+  const float scale = mx > 0.f ? mx / 127.0f : 1.0f;
+  float as = 0.f, ac = 0.f;
+  uint8_t *d = dst + (size_t)nt * KF * 256 + lane * 16 + j4;
+  for (int kf = 0; kf < KF; ++kf) {
+    int q = (int)rintf(s[(size_t)kf * 256 + tid] / scale);
+    q = q > 127 ? 127 : q < -127 ? -127 : q;
+    d[(size_t)(kf >> 2) * 1024 + 4 * (kf & 3)] = (uint8_t)(q + 128);
+    if (gam) {
+      const int k = 16 * kf + 4 * (lane >> 4) + j4;
+      as += (float)q * gam[k];
+      ac += (float)q * bet[k];
+    }
+  }
+  ps[tid] = as;
+  pc[tid] = ac;
+  __syncthreads();
+  if (tid < 16) {
+    const float sc = __int_as_float(smax[tid]) > 0.f ? __int_as_float(smax[tid]) / 127.0f : 1.0f;
+    wscale[16 * nt + tid] = sc;
+    if (gam) {
+      // the 16 holders of row `tid`: lanes tid, tid+16, tid+32, tid+48, four components each; fixed order
+      float ts = 0.f, tc = 0.f;
+      for (int g = 0; g < 4; ++g)
+        for (int c = 0; c < 4; ++c) {
+          ts += ps[(16 * g + tid) * 4 + c];
+          tc += pc[(16 * g + tid) * 4 + c];
+        }
+      const int n = 16 * nt + tid;
+      ln_s[n] = sc * ts;
+      ln_c[n] = sc * tc + ((bias && n < N) ? bias[n] : 0.f);
+    }
   }
 }
 

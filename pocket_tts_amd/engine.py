@@ -130,7 +130,12 @@ class MimiState:
 class Engine:
     """Weights of one model on one GPU + entry points of the hot path."""
 
-    def __init__(self, cfg: Config, weights: dict, device: str | torch.device = "cuda:0"):
+    QUANT_GROUPS = {"attention": 1, "ffn": 2}  # PTTS_QUANT_* (include/ptts.h)
+
+    def __init__(self, cfg: Config, weights: dict, device: str | torch.device = "cuda:0",
+                 quantize_groups: set | frozenset | None = None):
+        """`quantize_groups`: subset of {"attention", "ffn"} (the keys of the reference's
+        quantization.apply_dynamic_int8): those Linear layers of the FlowLM transformer get int8 weights."""
         self.lib = _lib.load()
         self.handle = None
         self._states = weakref.WeakSet()
@@ -162,7 +167,13 @@ class Engine:
         torch.cuda.synchronize(self.device)
         pc = make_ptts_config(cfg)
         h = C.c_void_p()
-        _lib.check(self.lib.ptts_create(C.byref(pc), arr, len(spec), self.device.index or 0, C.byref(h)))
+        flags = 0
+        for g in quantize_groups or ():
+            if g not in self.QUANT_GROUPS:
+                raise ValueError(f"unknown quantization group {g!r} (this build supports {sorted(self.QUANT_GROUPS)})")
+            flags |= self.QUANT_GROUPS[g]
+        self.quantize_groups = frozenset(quantize_groups or ())
+        _lib.check(self.lib.ptts_create_ex(C.byref(pc), arr, len(spec), self.device.index or 0, flags, C.byref(h)))
         self.handle = h
         del keep
         # All work is queued on a torch-owned stream passed through the ABI's `stream` argument, so torch's

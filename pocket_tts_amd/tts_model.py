@@ -120,15 +120,15 @@ class TTSModel:
         if config.suffix not in (".yaml", ".yml"):
             raise ValueError("Config should be a path to a YAML file ending with .yaml")
         cfg = load_config(config)
-        if quantize:
-            logger.warning("quantize=True: the int8 weight path is not built yet; running the fp32 path")
         weights = _load_weights(cfg)
         if tokenizer is None:
             tp = str(cfg.flow_lm.lookup_table.tokenizer_path)
             if not tp.startswith(("hf://", "http://", "https://")) and not Path(tp).exists() and (config.parent / tp).exists():
                 tp = str(config.parent / tp)  # relative to the YAML file
             tokenizer = SentencePieceTokenizer(cfg.flow_lm.lookup_table.n_bins, tp)
-        engine = Engine(cfg, weights, device)
+        # quantize=True: int8 weights for the reference's RECOMMENDED_CONFIG groups (quantization.py:21,
+        # tts_model.py:312-315); weight-only and per output channel here (see include/ptts.h)
+        engine = Engine(cfg, weights, device, quantize_groups={"attention", "ffn"} if quantize else None)
         return cls(engine, cfg, tokenizer, temp, lsd_decode_steps, noise_clamp, eos_threshold, origin=config)
 
     # ---- voice state ------------------------------------------------------------------------

@@ -126,3 +126,49 @@ def test_voice_encoder_matches_reference(golden, case):
             assert _maxerr(v, g["tap_" + k]) < ATOL, k
     assert _maxerr(lat, g["latent"]) < ATOL
     assert _maxerr(enc.conditioning(g["audio"]), g["conditioning"]) < ATOL
+
+
+def test_int8_weight_restatement_properties():
+    """oracle/np_oracle.py::quantized_weights (the scheme the GPU int8 path implements): per-row symmetric
+    int8, error <= scale / 2, idempotent, touches only the reference's "attention" and "ffn" Linear weights
+    (quantization.py:60-128), and the quantised model stays close to the fp32 one."""
+    cfg, W = synth_weights("tiny", 0)
+    Wq = O.quantized_weights(W)
+    changed = sorted(k for k in W if not np.array_equal(W[k], Wq[k]))
+    L = cfg.flow_lm.transformer.num_layers
+    assert len(changed) == 4 * L and all(k.startswith("flow_lm.transformer.layers.") for k in changed)
+    for k in changed:
+        w, q = W[k], Wq[k]
+        scale = np.abs(w).max(axis=1, keepdims=True) / 127.0
+        assert np.all(np.abs(w - q) <= scale * 0.5 * (1 + 1e-5))
+        assert np.array_equal(O.quantize_dequantize_int8(q), q)
+        assert len(np.unique(np.rint(q[0] / scale[0]))) <= 255
+    only_attn = O.quantized_weights(W, ("attention",))
+    assert np.array_equal(only_attn["flow_lm.transformer.layers.0.linear1.weight"], W["flow_lm.transformer.layers.0.linear1.weight"])
+    # end to end: a few AR steps, fp32 vs int8 weights
+    rng = np.random.default_rng(0)
+    emb = (rng.standard_normal((2, 9, cfg.flow_lm.transformer.d_model)) * 0.5).astype(np.float32)
+    outs = []
+    for w in (W, Wq):
+        lm = O.FlowLM(cfg, w)
+        st = lm.init_state(2, 16)
+        lm.prefill(st, emb)
+        x = np.full((2, lm.ldim), np.nan, np.float32)
+        seq = []
+        for _ in range(4):
+            x, _, _ = lm.decode_step(st, x, None, 1, -4.0)
+            seq.append(x.copy())
+        outs.append(np.stack(seq))
+    snr = 10 * np.log10((outs[0] ** 2).mean() / ((outs[0] - outs[1]) ** 2).mean())
+    assert snr > 15.0
+
+
+def test_reference_int8_snr_fixture():
+    """tests/golden/int8_reference_snr.json: what the reference's own dynamic-int8 path reaches against its fp32
+    path on the synthetic en100m weights (made by tests/golden/gen_int8_snr.py with the reference's modules)."""
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "int8_reference_snr.json")) as f:
+        d = json.load(f)
+    assert d["backend"] in ("torch.ao", "torchao") and 0 < d["latent_snr_db"] < d["first_step_latent_snr_db"] < 60
