@@ -109,6 +109,16 @@ const float *ptts_lm_latent_ptr(ptts_lm_state *s);
 int ptts_mimi_state_create(ptts_engine *e, int32_t batch, ptts_mimi_state **out);
 void ptts_mimi_state_destroy(ptts_mimi_state *s);
 int ptts_mimi_state_reset(ptts_mimi_state *s, void *stream);
+/* ---- continuous batching (the reference serves one request at a time, main.py:80-181) ----
+ * A batch state is a set of slots.  An utterance JOINS slot `row` with ptts_lm_state_copy_row (its prefilled
+ * batch-1 state) + ptts_mimi_state_reset_row (zero conv carries == init_states for that sequence,
+ * stateful_module.py:7-16) and LEAVES with ptts_lm_state_set_row_active(row, 0): a parked row keeps flowing
+ * through the batched kernels but stays at position 0.  Captured graphs stay valid across joins / leaves. */
+int ptts_mimi_state_reset_row(ptts_mimi_state *s, int32_t row, void *stream);
+int ptts_lm_state_set_row_active(ptts_lm_state *s, int32_t row, int32_t active, void *stream);
+/* 16-bit PCM straight from the codec's last kernel: (clamp(x, -1, 1) * 32767) truncated, the conversion of
+ * StreamingWAVWriter.write_pcm_data (data/audio.py:79).  i16[B, frame_samples], device or pinned host. */
+int ptts_mimi_set_pcm_i16(ptts_mimi_state *s, int16_t *d_pcm_i16);
 /* d_latent f32[B, ldim] (normalised FlowLM output) -> d_pcm f32[B, frame_samples]; includes the
  * emb_std/emb_mean de-normalisation, the quantizer 1x1 conv and increment_steps(mimi, 16). */
 int ptts_mimi_decode(ptts_engine *e, ptts_mimi_state *s, const float *d_latent, float *d_pcm, void *stream);

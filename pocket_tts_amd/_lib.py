@@ -65,6 +65,9 @@ PROTOTYPES = {
     "ptts_graph_capture_pipelined": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_float, _P, _P, _P, _P, _P, C.POINTER(_P)]),
     "ptts_graph_launch": (C.c_int, [_P, _P]),
     "ptts_graph_destroy": (None, [_P]),
+    "ptts_mimi_state_reset_row": (C.c_int, [_P, C.c_int32, _P]),
+    "ptts_lm_state_set_row_active": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "ptts_mimi_set_pcm_i16": (C.c_int, [_P, _P]),
     "ptts_tune": (C.c_int, [_P, C.c_int32, _P]),
     "ptts_tune_log": (C.c_char_p, [_P]),
     "ptts_tune_clear": (None, [_P]),

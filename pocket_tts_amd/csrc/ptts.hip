@@ -127,6 +127,9 @@ struct ptts_lm_state {
   float rng_std = 0.f;
   unsigned long long rng_seed = 0;
   int *rng_ctr = nullptr;
+  // continuous batching: parked rows (active[b] == 0) keep computing but do not advance their position
+  int *active = nullptr;
+  std::vector<int> h_active;
   size_t kv_plane() const { return (size_t)B * e->cfg.num_heads * cap * 64; }
   float *K(int l) { return kv + (size_t)(2 * l) * kv_plane(); }
   float *V(int l) { return kv + (size_t)(2 * l + 1) * kv_plane(); }
@@ -147,6 +150,7 @@ struct ptts_mimi_state {
   long c_stride[3], s_stride[3];
   int rows[4];  // rows per sequence at each SEANet stage
   float *pcm_dbg;
+  int16_t *pcm_i16 = nullptr;
   size_t kv_plane() const { return (size_t)B * e->cfg.m_heads * e->ring * 64; }
   float *K(int l) { return kv + (size_t)(2 * l) * kv_plane(); }
   float *V(int l) { return kv + (size_t)(2 * l + 1) * kv_plane(); }
@@ -865,6 +869,9 @@ extern "C" int ptts_lm_state_create(ptts_engine *e, int32_t B, int32_t t_cap, pt
   CHK(dallocT(nullptr, &s->eos_logit, B));
   CHK(dallocT(nullptr, &s->is_eos, B));
   CHK(dallocT(nullptr, &s->rng_ctr, 1));
+  CHK(dallocT(nullptr, &s->active, B));
+  s->h_active.assign(B, 1);
+  set_int_kernel<<<cdiv(B, 256), 256, 0, e->stream>>>(s->active, B, 1);
   fill_kernel<<<cdiv(B * c.ldim, 256), 256, 0, e->stream>>>(s->lat_prev, (long)B * c.ldim, NAN);
   HIPCHK(hipStreamSynchronize(e->stream));
   *out = s;
@@ -879,7 +886,7 @@ extern "C" void ptts_lm_state_destroy(ptts_lm_state *s) {
   free_scratch(&s->dec);
   if (s->pre.x) free_scratch(&s->pre);
   hipFree(s->xlat); hipFree(s->latfm); hipFree(s->c); hipFree(s->ce); hipFree(s->mod); hipFree(s->fx);
-  hipFree(s->fh); hipFree(s->f1); hipFree(s->lat); hipFree(s->lat_prev); hipFree(s->eos_logit); hipFree(s->is_eos); hipFree(s->rng_ctr);
+  hipFree(s->fh); hipFree(s->f1); hipFree(s->lat); hipFree(s->lat_prev); hipFree(s->eos_logit); hipFree(s->is_eos); hipFree(s->rng_ctr); hipFree(s->active);
   delete s;
 }
 
@@ -888,6 +895,8 @@ extern "C" int ptts_lm_state_reset(ptts_lm_state *s, void *stream) {
   set_int_kernel<<<cdiv(s->B, 256), 256, 0, st>>>(s->offset, s->B, 0);
   fill_kernel<<<cdiv(s->B * s->e->cfg.ldim, 256), 256, 0, st>>>(s->lat_prev, (long)s->B * s->e->cfg.ldim, NAN);
   std::fill(s->h_off.begin(), s->h_off.end(), 0);
+  std::fill(s->h_active.begin(), s->h_active.end(), 1);
+  set_int_kernel<<<cdiv(s->B, 256), 256, 0, st>>>(s->active, s->B, 1);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -965,15 +974,31 @@ extern "C" int ptts_lm_state_copy_row(ptts_lm_state *dst, int32_t row, const ptt
   hipStream_t st = S(dst->e, stream);
   const int T = src->h_off[0];
   if (T > dst->cap) return fail(-5, "copy_row: destination capacity too small");
-  for (int pl = 0; pl < c.num_layers * 2; ++pl)
-    for (int h = 0; h < c.num_heads; ++h) {
-      const float *sp = src->kv + ((size_t)pl * c.num_heads + h) * src->cap * 64;
-      float *dp = dst->kv + (((size_t)pl * dst->B + row) * c.num_heads + h) * dst->cap * 64;
-      if (T) HIPCHK(hipMemcpyAsync(dp, sp, (size_t)T * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
-    }
+  if (T) {
+    const long total = (long)c.num_layers * 2 * c.num_heads * T * 16;
+    kv_copy_row_kernel<<<cdiv(total, 256), 256, 0, st>>>(dst->kv, src->kv, c.num_layers * 2, c.num_heads, T, src->cap, dst->cap, dst->B, row);
+  }
   dst->h_off[row] = T;
+  dst->h_active[row] = 1;
+  set_int_kernel<<<1, 64, 0, st>>>(dst->active + row, 1, 1);
   set_int_kernel<<<1, 64, 0, st>>>(dst->offset + row, 1, T);
   fill_kernel<<<cdiv(c.ldim, 256), 256, 0, st>>>(dst->lat_prev + (size_t)row * c.ldim, (long)c.ldim, NAN);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Continuous batching: park / unpark one row.  A parked row still flows through the batched kernels (its
+// outputs are ignored by the caller) but its position is pinned to 0, so it never exhausts the KV capacity
+// and its attention reads one key.
+extern "C" int ptts_lm_state_set_row_active(ptts_lm_state *s, int32_t row, int32_t active, void *stream) {
+  if (!s || row < 0 || row >= s->B) return fail(-1, "set_row_active: row out of range");
+  hipStream_t st = S(s->e, stream);
+  s->h_active[row] = active ? 1 : 0;
+  set_int_kernel<<<1, 64, 0, st>>>(s->active + row, 1, active ? 1 : 0);
+  if (!active) {
+    s->h_off[row] = 0;
+    set_int_kernel<<<1, 64, 0, st>>>(s->offset + row, 1, 0);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1144,7 +1169,7 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
   SITE("lm.tail");
   {
     ProfScope ps(st, "step_tail", 8.0 * B, 0);
-    step_tail_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->offset, B, 1, s->rng_ctr);
+    step_tail_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->offset, B, 1, s->rng_ctr, s->active);
   }
   SITE("");
   return 0;
@@ -1158,7 +1183,7 @@ extern "C" int ptts_lm_decode_step(ptts_engine *e, ptts_lm_state *s, const float
   for (int b = 0; b < s->B; ++b)
     if (s->h_off[b] + 1 > s->cap) return fail(-5, "decode: KV cache capacity exceeded");
   CHK(lm_step_enqueue(S(e, stream), e, s, d_latent_in, d_noise, lsd_steps, eos_threshold, d_latent_out, d_eos_logit, d_is_eos));
-  for (auto &o : s->h_off) o += 1;
+  for (int b = 0; b < s->B; ++b) s->h_off[b] += s->h_active[b];
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1245,6 +1270,37 @@ extern "C" int ptts_mimi_state_reset(ptts_mimi_state *s, void *stream) {
   return 0;
 }
 
+// Continuous batching: zero the streaming carries of ONE sequence (a new utterance joins in `row`): the
+// previous-frame buffers its first frame will read as halo, and its position in the decoder transformer.
+extern "C" int ptts_mimi_state_reset_row(ptts_mimi_state *s, int32_t row, void *stream) {
+  if (!s || row < 0 || row >= s->B) return fail(-1, "reset_row: row out of range");
+  hipStream_t st = S(s->e, stream);
+  const int CF = s->e->cfg.m_dim / 16;
+  set_int_kernel<<<1, 64, 0, st>>>(s->offset + row, 1, 0);
+  for (int par = 0; par < 2; ++par) {
+    zero_row_fm_kernel<<<cdiv(CF * 16, 256), 256, 0, st>>>(s->zq + par * s->zq_stride, CF, row);
+    // 16-row tiles: a sequence owns whole tiles, i.e. one contiguous block of every FM buffer
+    const size_t tr = (size_t)s->tr_stride / s->B, a0 = (size_t)s->a0_stride / s->B;
+    HIPCHK(hipMemsetAsync(s->tr_out + par * s->tr_stride + row * tr, 0, tr * 4, st));
+    HIPCHK(hipMemsetAsync(s->a0 + par * s->a0_stride + row * a0, 0, a0 * 4, st));
+    for (int i = 0; i < 3; ++i) {
+      const size_t cs = (size_t)s->c_stride[i] / s->B, ss = (size_t)s->s_stride[i] / s->B;
+      HIPCHK(hipMemsetAsync(s->cbuf[i] + par * s->c_stride[i] + row * cs, 0, cs * 4, st));
+      HIPCHK(hipMemsetAsync(s->sbuf[i] + par * s->s_stride[i] + row * ss, 0, ss * 4, st));
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Optional 16-bit PCM output of the codec's last kernel (device or pinned host memory, [B, frame_samples]);
+// applies to the decodes / graph captures issued after the call.  NULL switches it off.
+extern "C" int ptts_mimi_set_pcm_i16(ptts_mimi_state *s, int16_t *d_pcm_i16) {
+  if (!s) return fail(-1, "null state");
+  s->pcm_i16 = d_pcm_i16;
+  return 0;
+}
+
 static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, const float *d_latent, float *d_pcm) {
   const ptts_config &c = e->cfg;
   bind_engine(e);
@@ -1326,12 +1382,12 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
   SITE("seanet.conv_last");
   a = mk_gemm(e->conv_last, xin, c.n_filters / 16, B * Tl / 16, B * Tl);
   a.Xdstride = xds; a.T = Tl; a.par = s->frame;
-  a.epi = EPI_PCM; a.pcm = d_pcm ? d_pcm : s->pcm_dbg;
+  a.epi = EPI_PCM; a.pcm = d_pcm ? d_pcm : s->pcm_dbg; a.pcm_i16 = s->pcm_i16;
   launch_gemm(st, a, PRE_NONE);
   SITE("mimi.tail");
   {
     ProfScope ps(st, "step_tail", 8.0 * B, 0);
-    step_tail_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->offset, B, st16, s->frame);
+    step_tail_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->offset, B, st16, s->frame, nullptr);
   }
   SITE("");
   return 0;
@@ -1588,7 +1644,7 @@ extern "C" int ptts_graph_launch(ptts_graph *g, void *stream) {
       if (g->lm->h_off[b] + 1 > g->lm->cap) return fail(-5, "decode: KV cache capacity exceeded");
   }
   HIPCHK(hipGraphLaunch(g->exec, S(e, stream)));
-  if (g->lm) for (auto &o : g->lm->h_off) o += 1;
+  if (g->lm) for (int b = 0; b < g->lm->B; ++b) g->lm->h_off[b] += g->lm->h_active[b];
   if (g->mimi) g->mimi->h_frame += 1;
   return 0;
 }

@@ -114,6 +114,7 @@ struct GemmArgs {
   int cout, stride;
   // EPI_PCM
   float *pcm;
+  int16_t *pcm_i16;  // optional 16-bit copy: (clamp(x, -1, 1) * 32767) truncated, as data/audio.py:79
 };
 
 template <int PRE>
@@ -220,7 +221,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 acc, int 
       *(f32x4 *)(y + idx) = act4(acc, a.act);
     } break;
     case EPI_PCM: {
-      if (g == 0 && m < a.M) a.pcm[m] = acc.x;
+      if (g == 0 && m < a.M) {
+        a.pcm[m] = acc.x;
+        if (a.pcm_i16) a.pcm_i16[m] = (int16_t)(fminf(fmaxf(acc.x, -1.0f), 1.0f) * 32767.0f);
+      }
     } break;
   }
 }
@@ -950,10 +954,18 @@ __global__ void add_int_kernel(int *p, int n, int inc) {
 }
 // end-of-step bookkeeping in one launch: offsets of all rows += inc (increment_steps, reference
 // stateful_module.py:19-26) and one scalar counter (noise counter / frame parity) += 1
-__global__ void step_tail_kernel(int *offset, int n, int inc, int *counter) {
+// `active` (optional): parked rows of a continuously batched state keep their offset
+__global__ void step_tail_kernel(int *offset, int n, int inc, int *counter, const int *active) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) offset[i] += inc;
+  if (i < n && (!active || active[i])) offset[i] += inc;
   if (i == 0 && counter) *counter += 1;
+}
+// zero row `row` of an FM buffer with F k-fragments per row tile (a joining utterance's codec carries)
+__global__ void zero_row_fm_kernel(float *buf, int F, int row) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;  // (kf, group, j4)
+  if (i >= F * 16) return;
+  const int kf = i >> 4, g = (i >> 2) & 3, j4 = i & 3;
+  buf[(((size_t)(row >> 4) * F + kf) * 64 + 16 * g + (row & 15)) * 4 + j4] = 0.f;
 }
 __global__ void set_int_kernel(int *p, int n, int v) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1296,6 +1308,20 @@ __global__ void kv_export_kernel(float *dst, const float *Kc, const float *Vc, i
 }
 
 // dst rows <- src rows (src batch 1 broadcasts), whole [L][2][B][H][cap][64] block, equal cap
+// one batch-1 state -> row `row` of a batch state: [planes][1][H][src_cap][64] -> [planes][B][H][dst_cap][64], T positions
+__global__ void kv_copy_row_kernel(float *dst, const float *src, int planes, int H, int T, int src_cap, int dst_cap,
+                                   int B, int row) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (plane, head, t, 16 float4)
+  if (i >= (long)planes * H * T * 16) return;
+  const int v = i & 15;
+  long r = i >> 4;
+  const int t = r % T; r /= T;
+  const int h = r % H;
+  const int pl = r / H;
+  const f32x4 x = *(const f32x4 *)(src + (((size_t)pl * H + h) * src_cap + t) * 64 + v * 4);
+  *(f32x4 *)(dst + ((((size_t)pl * B + row) * H + h) * dst_cap + t) * 64 + v * 4) = x;
+}
+
 __global__ void kv_copy_kernel(float *dst, const float *src, long per_row, int B, int srcB, int planes) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // float4 units over [planes][B][per_row/4]
   long pr4 = per_row / 4;

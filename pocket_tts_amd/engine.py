@@ -96,6 +96,10 @@ class LMState:
     def copy_from(self, src: "LMState"):
         _lib.check(self.engine.lib.ptts_lm_state_copy(self.handle, src.handle, self.engine._sp))
 
+    def set_row_active(self, row: int, active: bool):
+        """continuous batching: a parked row stays at position 0 (copy_row_from re-activates it)"""
+        _lib.check(self.engine.lib.ptts_lm_state_set_row_active(self.handle, row, int(bool(active)), self.engine._sp))
+
     def __del__(self):
         try:
             self.close()
@@ -119,6 +123,15 @@ class MimiState:
     def reset(self, stream: torch.cuda.Stream | None = None):
         sp = self.engine._sp if stream is None else C.c_void_p(stream.cuda_stream)
         _lib.check(self.engine.lib.ptts_mimi_state_reset(self.handle, sp))
+
+    def reset_row(self, row: int, stream: torch.cuda.Stream | None = None):
+        """zero the streaming carries of one sequence (a new utterance joins in `row`)"""
+        sp = self.engine._sp if stream is None else C.c_void_p(stream.cuda_stream)
+        _lib.check(self.engine.lib.ptts_mimi_state_reset_row(self.handle, row, sp))
+
+    def set_pcm_i16(self, buf: torch.Tensor | None):
+        """int16 copy of the PCM written by the decodes / graph captures issued after this call (None: off)"""
+        _lib.check(self.engine.lib.ptts_mimi_set_pcm_i16(self.handle, _ptr(buf) if buf is not None else None))
 
     def __del__(self):
         try:
@@ -392,7 +405,7 @@ class StepPipeline:
     """
 
     def __init__(self, eng: Engine, lm_state: LMState, mimi_state: MimiState, noise=None, lsd_steps: int = 1,
-                 eos_threshold: float = -4.0, mode: str | None = None):
+                 eos_threshold: float = -4.0, mode: str | None = None, pcm_i16: bool = False):
         self.eng, self.st, self.ms = eng, lm_state, mimi_state
         B, dev = lm_state.batch, eng.device
         self.mode = mode or ("hostsync" if B <= 8 else "events")
@@ -409,7 +422,13 @@ class StepPipeline:
         lib, H = eng.lib, eng.handle
         self.g_first = [eng.capture_lm_step(lm_state, noise, lsd_steps, eos_threshold, self.lat[p], self.logit[p],
                                             self.flag[p]) for p in range(2)]
-        self.g_last = [eng.capture_mimi(mimi_state, self.lat[p], self.pcm[p]) for p in range(2)]
+        # optional 16-bit PCM beside the fp32 one (the WAV sample format, data/audio.py:79), also pinned
+        self.pcm16 = [torch.zeros(B, eng.frame_samples, dtype=torch.int16).pin_memory() for _ in range(2)] if pcm_i16 else None
+        self.g_last = []
+        for p in range(2):
+            mimi_state.set_pcm_i16(self.pcm16[p] if pcm_i16 else None)
+            self.g_last.append(eng.capture_mimi(mimi_state, self.lat[p], self.pcm[p]))
+        mimi_state.set_pcm_i16(None)
         self.g_both = []
         if self.mode == "fork":
             for p in range(2):

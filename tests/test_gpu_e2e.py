@@ -176,3 +176,69 @@ def test_generate_audio_batch_validates_inputs(model):
         model.generate_audio_batch([state], ["a", "b"])
     with pytest.raises(ValueError):
         model.generate_audio_batch(state, ["   "])
+
+
+TEXTS = ["Hello world. This is a test.", "ok", "This is a longer sentence, with several clauses, to test it.",
+         "How are you today?", "Short one.", "Another request arrives while the others are running.", "Yes."]
+
+
+def test_continuous_batching_join_leave_matches_single(model, fx):
+    """7 requests through 3 slots: requests join as slots free up (different positions per row, codec carries of
+    a joining row zeroed, parked rows in between), each must reproduce the one-by-one result at temp 0."""
+    from pocket_tts_amd.batching import ContinuousBatcher
+
+    state = model.get_state_for_audio_prompt(G / "e2e_voice.safetensors")
+    singles = [model.generate_audio(state, t) for t in TEXTS]
+    cb = ContinuousBatcher(model, slots=3, capacity=512)
+    try:
+        reqs = [cb.submit(state, t) for t in TEXTS[:5]]
+        for _ in range(6):  # let the first ones run for a while, then two more arrive mid-flight
+            cb.step()
+        reqs += [cb.submit(state, t) for t in TEXTS[5:]]
+        cb.run_until_idle()
+        outs = [r.result() for r in reqs]
+    finally:
+        cb.close()
+    for t, a, b in zip(TEXTS, singles, outs):
+        assert a.shape == b.shape, (t, a.shape, b.shape)
+        assert np.abs(a.numpy() - b.numpy()).max() < 5e-4, t
+
+
+def test_continuous_batching_background_thread_i16_and_long_text(model, fx):
+    """Background scheduler thread, 16-bit PCM written by the codec's last kernel, and a multi-chunk text (its
+    chunks run one after the other from the voice state, tts_model.py:618-631)."""
+    from pocket_tts_amd.batching import ContinuousBatcher
+
+    state = model.get_state_for_audio_prompt(G / "e2e_voice.safetensors")
+    long_text = "Hello world. This is a test. How are you today? This is a longer sentence, with several clauses."
+    ref_long = model.generate_audio(state, long_text, max_tokens=12)
+    ref_short = model.generate_audio(state, "Short one.")
+    cb = ContinuousBatcher(model, slots=2, capacity=512, pcm_format="i16")
+    cb.start()
+    try:
+        r1 = cb.submit(state, long_text, max_tokens=12)
+        r2 = cb.submit(state, "Short one.")
+        chunks = list(r2)
+        assert all(c.dtype == torch.int16 and c.shape == (1920,) for c in chunks)
+        o2 = torch.cat(chunks)
+        o1 = r1.result()
+    finally:
+        cb.close()
+    for ref, got in ((ref_long, o1), (ref_short, o2)):
+        assert ref.shape == got.shape
+        want = (ref.clamp(-1, 1) * 32767).short()   # StreamingWAVWriter.write_pcm_data (data/audio.py:79)
+        assert (want.int() - got.int()).abs().max() <= 16  # 5e-4 * 32767
+
+
+def test_continuous_batching_rejects_oversized_request(model):
+    from pocket_tts_amd.batching import ContinuousBatcher
+
+    state = model.get_state_for_audio_prompt(G / "e2e_voice.safetensors")
+    cb = ContinuousBatcher(model, slots=2, capacity=64)
+    try:
+        with pytest.raises(ValueError):
+            cb.submit(state, "This request cannot fit the slot capacity because it needs many frames.")
+        with pytest.raises(ValueError):
+            cb.submit(state, "   ")
+    finally:
+        cb.close()
