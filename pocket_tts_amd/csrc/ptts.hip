@@ -403,7 +403,18 @@ static bool cfg_valid(int cfg, const GemmArgs &a, int pre) {
   return true;
 }
 
-static void launch_by_cfg(hipStream_t st, const GemmArgs &a, int pre, int cfg) {
+// XCD-aware mapping (tile_of_block) when the activations outweigh the weights and several column blocks re-read them
+static int swz_for(int cfg, const GemmArgs &a) {
+  static const int swz_env = [] { const char *v = getenv("PTTS_SWZ"); return v ? atoi(v) : -1; }();
+  const int *sh = kCfgShape[cfg];
+  const int gx = sh[2] == 0 ? cdiv(a.NT, sh[0]) : cdiv(a.NT, sh[0] * sh[3]);
+  if (gx <= 1) return 0;
+  return swz_env >= 0 ? swz_env : (a.M > a.NT * 16 && a.MT >= 64);
+}
+
+static void launch_by_cfg(hipStream_t st, const GemmArgs &a_in, int pre, int cfg) {
+  GemmArgs a = a_in;
+  a.swz = swz_for(cfg, a);
   if (a.Wq) {
     switch (cfg) {
       case 0: launch_cfg_q8<1, 1, 8, 1, 1>(st, a, pre); break;

@@ -59,6 +59,7 @@ struct GemmArgs {
   // per lane carries the lane's operands of FOUR consecutive k-fragments; y[n] = wscale[n] * sum_k q[n][k] x[k]
   const uint8_t *Wq;
   const float *wscale;
+  int swz;  // XCD-aware workgroup -> tile mapping (tile_of_block)
   const float *ln_g;  // Q8 + PRE_LNFOLD: the LayerNorm gain stays out of the quantised matrix and scales x on load
   int NT, KF, CF, ntaps;
   // input FM view; double-buffered by frame parity when Xdstride != 0
@@ -116,6 +117,22 @@ struct GemmArgs {
   float *pcm;
   int16_t *pcm_i16;  // optional 16-bit copy: (clamp(x, -1, 1) * 32767) truncated, as data/audio.py:79
 };
+
+// Workgroup -> tile mapping.  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs (ids b and
+// b + 8 share an L2).  With `swz` the linear id is permuted so that each XCD owns one CONTIGUOUS run of tiles in
+// (row block, column block) order: the column blocks that re-read the same X rows then sit behind one L2 instead of
+// up to 8.  Used when the activations are the larger operand (codec convs); decode GEMMs keep the identity
+// mapping, under which the row blocks sharing a weight tile already share an XCD (grid.x is a multiple of 8).
+__device__ __forceinline__ void tile_of_block(int swz, int &bx, int &by) {
+  bx = blockIdx.x;
+  by = blockIdx.y;
+  if (!swz) return;
+  const int gx = gridDim.x, per = (gx * gridDim.y) >> 3;
+  int bid = by * gx + bx;
+  if (bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
+  by = bid / gx;
+  bx = bid - by * gx;
+}
 
 template <int PRE>
 __device__ __forceinline__ f32x4 pre4(f32x4 x, const float *prevec, int kf, int lane) {
@@ -238,8 +255,10 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
   const int wk = wave % WK;
   const int wn = (wave / WK) % WN;
   const int wm = wave / (WK * WN);
-  const int nt0 = (blockIdx.x * WN + wn) * TN;
-  const int mt0 = (blockIdx.y * WM + wm) * TM;
+  int bx, by;
+  tile_of_block(a.swz, bx, by);
+  const int nt0 = (bx * WN + wn) * TN;
+  const int mt0 = (by * WM + wm) * TM;
   const int par = a.par ? (*a.par & 1) : 0;
   const float *Xc = a.X + par * a.Xdstride;
   const float *Xp = a.X + (par ^ 1) * a.Xdstride;
@@ -548,23 +567,35 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
 // LDS-staged variant for the large-M GEMMs of the codec (rows = sequences x time).  A workgroup of 4 waves
 // (2 x 2) owns BMT x BNT 16x16 tiles.  Per stage of KC k-fragments every operand fragment is copied ONCE per
 // workgroup by `global_load_lds_dwordx4` (1 KiB, wave-linear = exactly the FM / packed fragment image, no VGPRs),
-// then each wave reads its fragments with conflict-free ds_read_b128.  Two stages: the DMA of stage s+1 is in
-// flight while stage s feeds the MFMAs; one barrier per stage.
+// then each wave reads its fragments with conflict-free ds_read_b128 (all reads of a stage issued before its
+// MFMAs).  The DMA of stage s+1 is in flight while stage s feeds the MFMAs; one barrier per stage.
 // ---------------------------------------------------------------------------------------------
 #define GLDS16(gptr, lptr)                                                                      \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),      \
                                    (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
 
-template <int BMT, int BNT, int KC, int PRE>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BMT, int BNT, int KC, int PRE, int NS = 2>
 __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
-  static_assert(BMT % 4 == 0 && BNT % 2 == 0, "tile shape");
+  static_assert(BMT % 4 == 0 && BNT % 2 == 0 && (BNT * KC) % 4 == 0, "tile shape");
+  static_assert(NS >= 2 && NS <= 4, "stage count");
   constexpr int WMT = BMT / 2, WNT = BNT / 2;  // tiles per wave
   constexpr int NX = BMT * KC, NFRAG = (BMT + BNT) * KC;
   constexpr int XPW = BMT / 4;  // distinct m-tiles a loader wave touches (fragment f -> wave f % 4)
-  __shared__ f32x4 lds[2][NFRAG][64];
+  constexpr int IPS = NFRAG / 4;  // DMA instructions per stage and wave
+  // NS-deep ring: NS - 1 stages are in flight while one feeds the MFMAs.  Measured (tests/hip/bench_lds_ring.hip):
+  // 3 or 4 stages are never faster than 2 on the codec shapes and cost occupancy, so 2 is the default.
+  __shared__ f32x4 lds[NS][NFRAG][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int mt0 = blockIdx.y * BMT, nt0 = blockIdx.x * BNT;
+  int bx, by;
+  tile_of_block(a.swz, bx, by);
+  const int mt0 = by * BMT, nt0 = bx * BNT;
   const int par = a.par ? (*a.par & 1) : 0;
   const float *Xc = a.X + par * a.Xdstride;
   const float *Xp = a.X + (par ^ 1) * a.Xdstride;
@@ -629,19 +660,28 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
   for (int j = 0; j < WMT; ++j) sx[j] = sxx[j] = 0.f;
 
   const int nst = a.KF / KC;  // host guarantees KF % KC == 0
-  issue(0, 0);
-  for (int s = 0; s < nst; ++s) {
-    const int cur = s & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of stage s has landed
-    __syncthreads();                                   // ... everyone's has, and buffer cur^1 is free again
-    if (s + 1 < nst) issue((s + 1) * KC, cur ^ 1);
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-      f32x4 x[WMT], w[WNT];
+  for (int p = 0; p < NS - 1; ++p)
+    if (p < nst) issue(p * KC, p);
+  for (int s = 0; s < nst; ++s) {
+    const int cur = s % NS;
+    // this wave's DMA of stage s has landed once at most `ahead` later stages' instructions are outstanding
+    const int ahead = min(NS - 2, nst - 1 - s);
+    if (ahead >= 2) wait_vmcnt<2 * IPS>();
+    else if (ahead == 1) wait_vmcnt<IPS>();
+    else wait_vmcnt<0>();
+    __syncthreads();  // ... everyone's has, and the buffer of stage s-1 is free again
+    if (s + NS - 1 < nst) issue((s + NS - 1) * KC, (s + NS - 1) % NS);
+    // LDS reads are register double-buffered: the fragments of k-step kc+1 are read while the MFMAs of kc run
+    // (with one wave per SIMD nothing else would cover the ~128-cycle ds_read latency)
+    f32x4 xa[WMT], wa[WNT], xb[WMT], wb[WNT];
+    auto rd = [&](int kc, f32x4 *x, f32x4 *w) {
 #pragma unroll
       for (int j = 0; j < WMT; ++j) x[j] = lds[cur][kc * BMT + wm * WMT + j][lane];
 #pragma unroll
       for (int i = 0; i < WNT; ++i) w[i] = lds[cur][NX + kc * BNT + wn * WNT + i][lane];
+    };
+    auto mm = [&](const f32x4 *x, const f32x4 *w) {
       if constexpr (PRE == PRE_LNFOLD) {
 #pragma unroll
         for (int j = 0; j < WMT; ++j) {
@@ -656,6 +696,20 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
 #pragma unroll
           for (int j = 0; j < WMT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][cidx], x[j][cidx], acc[i][j], 0, 0, 0);
+    };
+    rd(0, xa, wa);
+#pragma unroll
+    for (int kc = 0; kc < KC; kc += 2) {
+      // sched_barrier: keep the reads ahead of the MFMAs they overlap (the scheduler otherwise sinks them to
+      // save registers and the pipe idles behind s_waitcnt lgkmcnt(0))
+      if (kc + 1 < KC) rd(kc + 1, xb, wb);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(xa, wa);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kc + 2 < KC) rd(kc + 2, xa, wa);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kc + 1 < KC) mm(xb, wb);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
@@ -1160,7 +1214,6 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
   const float *Vb = a.Vc + (size_t)bh * a.cap * 64;
   const int pq = q0 + c;
 
-  f32x4 kn[4], vn[4];
   auto load_tile = [&](int tile, f32x4 *kk, f32x4 *vv) {
     const int p0 = tile * 16;
     const int slot0 = a.ring ? (p0 % a.ring) : p0;
@@ -1169,14 +1222,8 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) vv[r] = *(const f32x4 *)(Vb + (size_t)(slot0 + 4 * g + r) * 64 + 4 * c);
   };
-  if (ts < te) load_tile(ts, kn, vn);
-  for (int tile = ts; tile < te; ++tile) {
+  auto process = [&](int tile, const f32x4 *kf4, const f32x4 *vf4) {
     const int p0 = tile * 16;
-    f32x4 kf4[4], vf4[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { kf4[i] = kn[i]; vf4[i] = vn[i]; }
-    // the next tile's K/V are in flight while this tile's scores, softmax and P.V run
-    if (tile + 1 < te) load_tile(tile + 1, kn, vn);
     // four independent accumulators (one per 16-wide slice of d), issued round-robin: no MFMA waits for
     // the 40-cycle dependent-accumulator latency
     f32x4 sp[4];
@@ -1226,6 +1273,22 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
       o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], vf4[r].z, o[2], 0, 0, 0);
       o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], vf4[r].w, o[3], 0, 0, 0);
     }
+  };
+  // Three rotating register tiles: the K/V of the next TWO key tiles (16 KB per wave) are in flight while a tile's
+  // scores, softmax and P.V run.  A decode step streams the whole cache once with ~4 waves per CU, so bytes in
+  // flight per wave are what sets the achieved HBM rate.
+  f32x4 k0[4], v0[4], k1[4], v1[4], k2[4], v2[4];
+  if (ts < te) load_tile(ts, k0, v0);
+  if (ts + 1 < te) load_tile(ts + 1, k1, v1);
+  for (int tile = ts; tile < te; tile += 3) {
+    if (tile + 2 < te) load_tile(tile + 2, k2, v2);
+    process(tile, k0, v0);
+    if (tile + 1 >= te) break;
+    if (tile + 3 < te) load_tile(tile + 3, k0, v0);
+    process(tile + 1, k1, v1);
+    if (tile + 2 >= te) break;
+    if (tile + 4 < te) load_tile(tile + 4, k1, v1);
+    process(tile + 2, k2, v2);
   }
 
   if (a.splits == 1) {

@@ -191,7 +191,7 @@ class Engine:
         del keep
         # All work is queued on a torch-owned stream passed through the ABI's `stream` argument, so torch's
         # caching allocator (record_stream) and the library agree on one stream whose lifetime torch manages.
-        self.stream = torch.cuda.Stream(device=self.device)
+        self.stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("PTTS_PRIO_LM", "0")))
         self._sp = C.c_void_p(self.stream.cuda_stream)
         t = cfg.flow_lm.transformer
         self.D, self.H, self.L = t.d_model, t.num_heads, t.num_layers
@@ -415,7 +415,7 @@ class StepPipeline:
         self.pcm = [torch.zeros(B, eng.frame_samples).pin_memory() for _ in range(2)]
         self.ev = [torch.cuda.Event() for _ in range(2)]    # codec frame (f & 1) complete -> pcm_of(f) valid
         self.ev_lm = [torch.cuda.Event() for _ in range(2)]  # FlowLM step (t & 1) complete -> flag valid
-        self.s2 = torch.cuda.Stream(device=dev)
+        self.s2 = torch.cuda.Stream(device=dev, priority=int(os.environ.get("PTTS_PRIO_CODEC", "0")))
         eng.sync()
         torch.cuda.synchronize(dev)
         eng.tune(B)  # before capture: graphs freeze the tile choices

@@ -1,0 +1,86 @@
+// Tile-configuration sweep of gemm_kernel over the hot-path GEMM shapes (run on MI355X):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tests/hip/sweep_gemm tests/hip/sweep_gemm.hip && tests/hip/sweep_gemm
+// Prints one line per (shape, config) with the time of a back-to-back launch, best config first.
+#include "../../pocket_tts_amd/csrc/ptts_kernels.h"
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+static int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static float *g_buf; static hipStream_t g_st;
+struct Res { std::string cfg; double us; int gx, gy; };
+template <int TN, int TM, int WK, int WN, int WM>
+static void run(std::vector<Res> &out, int M, int N, int K, int ntaps, int T) {
+  int MT = cdiv(M, 16), NT = cdiv(N, 16), CF = K / 16, KF = CF * ntaps;
+  if (WK > 1 && KF < 2 * WK) return;           // nothing to split
+  if (TM * WM > 2 * MT || TN * WN > 2 * NT) return;  // mostly padding
+  size_t wsz = (size_t)NT * KF * 256, xsz = (size_t)MT * CF * 256, ysz = (size_t)MT * NT * 256;
+  if ((wsz + 2 * xsz + ysz + 64) * 4 > ((size_t)3 << 30)) return;
+  GemmArgs a; memset(&a, 0, sizeof a);
+  a.W = g_buf; a.X = g_buf + wsz; a.Y = g_buf + wsz + 2 * xsz; a.Xdstride = ntaps > 1 ? xsz : 0;
+  a.par = ntaps > 1 ? (int *)(g_buf + wsz + 2 * xsz + ysz) : nullptr;
+  a.NT = NT; a.KF = KF; a.CF = CF; a.ntaps = ntaps; a.XF = CF; a.MT = MT; a.M = M; a.T = T; a.epi = EPI_STORE; a.YF = NT; a.xstride = 1; a.halo = ntaps - 1;
+  dim3 grid(cdiv(NT, TN * WN), cdiv(MT, TM * WM));
+  auto launch = [&] { gemm_kernel<TN, TM, WK, WN, WM, PRE_NONE><<<grid, 64 * WK * WN * WM, 0, g_st>>>(a); };
+  for (int i = 0; i < 3; ++i) launch();
+  hipStreamSynchronize(g_st);
+  const int R = 20;
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < R; ++i) launch();
+  hipStreamSynchronize(g_st);
+  double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / R;
+  char nm[64]; snprintf(nm, sizeof nm, "<%d,%d,%d,%d,%d>", TN, TM, WK, WN, WM);
+  out.push_back({nm, us, (int)grid.x, (int)grid.y});
+}
+template <int BMT, int BNT, int KC, int NS>
+static void run_lds(std::vector<Res> &out, int M, int N, int K, int ntaps, int T) {
+  int MT = cdiv(M, 16), NT = cdiv(N, 16), CF = K / 16, KF = CF * ntaps;
+  if (KF % KC || BMT > 2 * MT || BNT > 2 * NT) return;
+  size_t wsz = (size_t)NT * KF * 256, xsz = (size_t)MT * CF * 256, ysz = (size_t)MT * NT * 256;
+  if ((wsz + 2 * xsz + ysz + 64) * 4 > ((size_t)3 << 30)) return;
+  GemmArgs a; memset(&a, 0, sizeof a);
+  a.W = g_buf; a.X = g_buf + wsz; a.Y = g_buf + wsz + 2 * xsz; a.Xdstride = ntaps > 1 ? xsz : 0;
+  a.par = ntaps > 1 ? (int *)(g_buf + wsz + 2 * xsz + ysz) : nullptr;
+  a.NT = NT; a.KF = KF; a.CF = CF; a.ntaps = ntaps; a.XF = CF; a.MT = MT; a.M = M; a.T = T; a.epi = EPI_STORE; a.YF = NT; a.xstride = 1; a.halo = ntaps - 1;
+  dim3 grid(cdiv(NT, BNT), cdiv(MT, BMT));
+  auto launch = [&] { gemm_lds_kernel<BMT, BNT, KC, PRE_NONE, NS><<<grid, 256, 0, g_st>>>(a); };
+  for (int i = 0; i < 3; ++i) launch();
+  hipStreamSynchronize(g_st);
+  const int R = 20;
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < R; ++i) launch();
+  hipStreamSynchronize(g_st);
+  double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / R;
+  char nm[64]; snprintf(nm, sizeof nm, "LDS<%d,%d,%d|ns%d>", BMT, BNT, KC, NS);
+  out.push_back({nm, us, (int)grid.x, (int)grid.y});
+}
+static void sweep(const char *name, int M, int N, int K, int ntaps, int T) {
+  std::vector<Res> r;
+  run_lds<4, 4, 2, 2>(r, M, N, K, ntaps, T); run_lds<4, 4, 2, 3>(r, M, N, K, ntaps, T); run_lds<4, 4, 2, 4>(r, M, N, K, ntaps, T);
+  run_lds<4, 8, 2, 2>(r, M, N, K, ntaps, T); run_lds<4, 8, 2, 3>(r, M, N, K, ntaps, T); run_lds<4, 8, 2, 4>(r, M, N, K, ntaps, T);
+  run_lds<8, 8, 2, 2>(r, M, N, K, ntaps, T); run_lds<8, 8, 2, 3>(r, M, N, K, ntaps, T); run_lds<8, 8, 2, 4>(r, M, N, K, ntaps, T);
+  run_lds<4, 2, 2, 2>(r, M, N, K, ntaps, T); run_lds<4, 2, 2, 4>(r, M, N, K, ntaps, T);
+  run_lds<4, 4, 4, 2>(r, M, N, K, ntaps, T); run_lds<4, 4, 4, 3>(r, M, N, K, ntaps, T);
+  run_lds<8, 4, 2, 4>(r, M, N, K, ntaps, T);
+  run<2, 4, 4, 1, 1>(r, M, N, K, ntaps, T); run<2, 4, 1, 2, 2>(r, M, N, K, ntaps, T);
+  double fl = 2.0 * M * N * (double)K * ntaps;
+  printf("%-18s M=%-6d N=%-5d K=%dx%-4d |", name, M, N, ntaps, K);
+  for (size_t i = 0; i < r.size(); ++i) printf(" %s %.1f", r[i].cfg.c_str(), r[i].us);
+  std::sort(r.begin(), r.end(), [](const Res &a, const Res &b) { return a.us < b.us; });
+  printf(" | best %s %.1f TF\n", r[0].cfg.c_str(), fl / r[0].us * 1e-6);
+}
+int main() {
+  hipStreamCreate(&g_st);
+  hipMalloc(&g_buf, (size_t)3 << 30); hipMemset(g_buf, 0, (size_t)3 << 30);
+  {
+    int R = 16 * 64;
+    sweep("mimi.qkv", R, 1536, 512, 1, 16); sweep("mimi.ff1", R, 2048, 512, 1, 16); sweep("mimi.ff2", R, 512, 2048, 1, 16);
+    sweep("seanet.conv0", R, 512, 512, 7, 16); sweep("seanet.convtr1", R, 1536, 512, 2, 16);
+    sweep("seanet.res1a", 6 * R, 128, 256, 3, 96); sweep("seanet.convtr2", 6 * R, 640, 256, 2, 96);
+    sweep("seanet.res2a", 30 * R, 64, 128, 3, 480); sweep("seanet.convtr3", 30 * R, 256, 128, 2, 480);
+    sweep("seanet.res3a", 120 * R, 32, 64, 3, 1920); sweep("seanet.res3b", 120 * R, 64, 32, 1, 1920);
+  }
+  return 0;
+}
