@@ -156,6 +156,10 @@ void ptts_graph_destroy(ptts_graph *g);
 int ptts_tune(ptts_engine *e, int32_t batch, void *stream);
 const char *ptts_tune_log(ptts_engine *e);
 void ptts_tune_clear(ptts_engine *e);
+/* The tuned table as text (one line per GEMM shape) so that a deployment tunes once: export after ptts_tune,
+ * import (returns the number of entries accepted) before capturing graphs in a later process. */
+int64_t ptts_tune_export(ptts_engine *e, char *h_out, int64_t capacity);
+int ptts_tune_import(ptts_engine *e, const char *text);
 
 /* ---- utilities */
 int ptts_sync(ptts_engine *e, void *stream);

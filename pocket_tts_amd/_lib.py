@@ -71,6 +71,8 @@ PROTOTYPES = {
     "ptts_tune": (C.c_int, [_P, C.c_int32, _P]),
     "ptts_tune_log": (C.c_char_p, [_P]),
     "ptts_tune_clear": (None, [_P]),
+    "ptts_tune_export": (C.c_int64, [_P, C.c_char_p, C.c_int64]),
+    "ptts_tune_import": (C.c_int, [_P, C.c_char_p]),
     "ptts_sync": (C.c_int, [_P, _P]),
     "ptts_engine_stream": (_P, [_P]),
     "ptts_copy_to_host_async": (C.c_int, [_P, _P, _P, C.c_int64, _P]),

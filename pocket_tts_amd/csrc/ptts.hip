@@ -479,8 +479,15 @@ static int tune_one(hipStream_t st, const GemmArgs &a, int pre, Tuner &t) {
   int best = pick_cfg(a);
   float best_ms = 1e30f, heur_ms = 0.f;
   const int heur = best;
+  // PTTS_TUNE_EXCLUDE="9,12": experiment knob, drops configurations from the search
+  static const unsigned excl = [] {
+    unsigned m = 0;
+    if (const char *v = getenv("PTTS_TUNE_EXCLUDE"))
+      for (const char *p = v; *p;) { m |= 1u << (atoi(p) & 31); while (*p && *p != ',') ++p; if (*p) ++p; }
+    return m;
+  }();
   for (int cfg = 0; cfg < kNumCfg; ++cfg) {
-    if (!cfg_valid(cfg, a, pre)) continue;
+    if (!cfg_valid(cfg, a, pre) || ((excl >> cfg) & 1)) continue;
     float ms_min = 1e30f;
     for (int r = 0; r < 4; ++r) {
       if (t.flush) flush_read_kernel<<<4096, 256, 0, st>>>((const f32x4 *)t.flush, t.flush_bytes / 16, (float *)t.flush);
@@ -1452,6 +1459,46 @@ extern "C" int ptts_tune(ptts_engine *e, int32_t B, void *stream) {
 }
 
 extern "C" const char *ptts_tune_log(ptts_engine *e) { return e ? e->tuner->log.c_str() : ""; }
+
+// The tuned table as text, one line per shape: the 12 key integers (tune_key) then the configuration index.
+extern "C" int64_t ptts_tune_export(ptts_engine *e, char *h_out, int64_t capacity) {
+  if (!e) return fail(-1, "null engine");
+  std::string out;
+  char line[256];
+  for (auto &kv : e->tuner->table) {
+    int n = 0;
+    for (int v : kv.first) n += snprintf(line + n, sizeof line - n, "%d ", v);
+    snprintf(line + n, sizeof line - n, "%d\n", kv.second);
+    out += line;
+  }
+  if ((int64_t)out.size() + 1 > capacity) return fail(-1, "tune_export: buffer too small");
+  memcpy(h_out, out.c_str(), out.size() + 1);
+  return (int64_t)out.size();
+}
+
+extern "C" int ptts_tune_import(ptts_engine *e, const char *text) {
+  if (!e || !text) return fail(-1, "null argument");
+  const char *p = text;
+  int n_ok = 0;
+  while (*p) {
+    TuneKey k;
+    int cfg = -1, consumed = 0, ok = 1;
+    for (int i = 0; i < 12 && ok; ++i) {
+      if (sscanf(p, "%d%n", &k[i], &consumed) != 1) ok = 0;
+      else p += consumed;
+    }
+    if (ok && sscanf(p, "%d%n", &cfg, &consumed) == 1) {
+      p += consumed;
+      if (cfg >= 0 && cfg < kNumCfg) { e->tuner->table[k] = cfg; ++n_ok; }
+    } else {
+      ok = 0;
+    }
+    while (*p && *p != '\n') ++p;
+    if (*p) ++p;
+    if (!ok && !*p) break;
+  }
+  return n_ok;
+}
 
 extern "C" void ptts_tune_clear(ptts_engine *e) {
   if (e) { e->tuner->table.clear(); e->tuner->log.clear(); }

@@ -233,9 +233,25 @@ class Engine:
         engine and batch; `PTTS_NO_TUNE=1` keeps the static heuristic).  Returns the tuner's log."""
         if os.environ.get("PTTS_NO_TUNE") == "1" or (batch in self._tuned and not force):
             return ""
+        # PTTS_TUNE_CACHE=<file>: tile choices are read from / appended to a text file, so that a deployment (or
+        # a profiling run, whose counters would perturb the timings) reuses the choices of an earlier process
+        cache = os.environ.get("PTTS_TUNE_CACHE")
+        tag = f"# batch {int(batch)}\n"
+        if cache and os.path.exists(cache) and not force:
+            text = open(cache).read()
+            if tag in text:
+                self.lib.ptts_tune_import(self.handle, text.encode())
+                self._tuned.add(batch)
+                return ""
         self._pre()
         _lib.check(self.lib.ptts_tune(self.handle, int(batch), self._sp))
         self._tuned.add(batch)
+        if cache:
+            buf = C.create_string_buffer(1 << 20)
+            n = self.lib.ptts_tune_export(self.handle, buf, len(buf))
+            _lib.check(int(n))
+            with open(cache, "a") as f:
+                f.write(tag + buf.value.decode())
         return (self.lib.ptts_tune_log(self.handle) or b"").decode()
 
     def profile_start(self):

@@ -330,3 +330,26 @@ def test_tuned_tiles_match_static_choice(cfg_name, B):
         assert np.allclose(a, b, atol=2e-5, rtol=1e-5)
         assert np.allclose(la, lb, atol=5e-5, rtol=1e-5)
         assert np.allclose(pa, pb, atol=2e-5, rtol=1e-5)
+
+
+def test_tuned_table_export_import_roundtrip(tmp_path, monkeypatch):
+    """PTTS_TUNE_CACHE: the choices of one process are reused by the next (same table, no second tuning pass)."""
+    import ctypes as C
+
+    eng = get_engine("tiny")
+    eng.lib.ptts_tune_clear(eng.handle)
+    eng._tuned.clear()
+    cache = tmp_path / "tune.txt"
+    monkeypatch.setenv("PTTS_TUNE_CACHE", str(cache))
+    log = eng.tune(5)
+    assert log and cache.exists()
+    buf = C.create_string_buffer(1 << 20)
+    n1 = eng.lib.ptts_tune_export(eng.handle, buf, len(buf))
+    table1 = buf.value.decode()
+    assert n1 > 0 and len(table1.splitlines()) >= 20
+    eng.lib.ptts_tune_clear(eng.handle)
+    eng._tuned.clear()
+    assert eng.tune(5) == ""  # served from the cache file: nothing is measured
+    eng.lib.ptts_tune_export(eng.handle, buf, len(buf))
+    assert buf.value.decode() == table1
+    assert eng.lib.ptts_tune_import(eng.handle, b"garbage line\n1 2 3\n") == 0

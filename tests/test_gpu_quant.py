@@ -94,3 +94,36 @@ def test_int8_snr_against_fp32():
         with open(path) as f:
             floor = json.load(f)["latent_snr_db"] - 3.0
     assert snr_lat > floor and snr_pcm > 10.0
+
+
+def test_load_model_quantize_flag_end_to_end(tmp_path):
+    """The reference's tests/test_quantization.py on this build: `load_model(quantize=True)` produces valid audio
+    (not silent, finite), really switches the FlowLM attention/FFN weights to int8, and the CLI accepts --quantize."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    from pocket_tts_amd import TTSModel
+
+    G = Path(__file__).parent / "golden"
+    mq = TTSModel.load_model(config=G / "e2e_tiny.yaml", temp=0.0, quantize=True)
+    mb = TTSModel.load_model(config=G / "e2e_tiny.yaml", temp=0.0, quantize=False)
+    try:
+        assert mq.engine.quantize_groups == {"attention", "ffn"} and mb.engine.quantize_groups == frozenset()
+        assert mq.engine.lm_weight_bytes() < mb.engine.lm_weight_bytes()
+        state = mq.get_state_for_audio_prompt(G / "e2e_voice.safetensors")
+        audio = mq.generate_audio(state, "Hello, this is a test.")
+        ref = mb.generate_audio(mb.get_state_for_audio_prompt(G / "e2e_voice.safetensors"), "Hello, this is a test.")
+        assert len(audio) > 0 and torch.isfinite(audio).all() and audio.abs().max() > 0
+        n = min(len(audio), len(ref))
+        assert n > 0 and _snr_db(ref[:n].numpy(), audio[:n].numpy()) > 5.0
+    finally:
+        mq.engine.close()
+        mb.engine.close()
+    out = tmp_path / "q.wav"
+    r = subprocess.run([sys.executable, "-m", "pocket_tts_amd", "generate", "--quantize", "--config", str(G / "e2e_tiny.yaml"),
+                        "--voice", str(G / "e2e_voice.safetensors"), "--text", "Hello, this is a test.",
+                        "--output-path", str(out), "-q"], capture_output=True, text=True, timeout=600,
+                       cwd=str(Path(__file__).parent.parent))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out.exists() and out.stat().st_size > 1000
