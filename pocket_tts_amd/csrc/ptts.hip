@@ -622,7 +622,8 @@ static void run_tr_layer(hipStream_t st, const TrLayer &T, const TrCtx &c) {
   {
     // K and V rows of every attended key once per head + q in + o out
     ProfScope ps(st, "attn", c.kv_keys * c.H * 64 * 4 * 2 + 8.0 * c.M * c.D, 4.0 * c.kv_keys * c.H * 64 * std::min(c.Tq, 16));
-    attn_kernel<<<dim3(BH, c.QB, c.splits), 64, 0, st>>>(at);
+    if (c.Tq == 1) attn_decode_kernel<<<dim3(BH, 1, c.splits), 64, 0, st>>>(at);  // one query: vector ALU + wave reductions
+    else attn_kernel<<<dim3(BH, c.QB, c.splits), 64, 0, st>>>(at);
   }
   if (c.splits > 1) {
     ProfScope ps(st, "attn_combine", (double)BH * c.QB * c.splits * 16 * ATT_PSTRIDE * 4, 0);

@@ -357,22 +357,25 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
       if constexpr (PTTS_ABLATE & 1) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) x[u][j] = (f32x4){1.f, (float)lane, 3.f, (float)kf};
-      } else if (a.ntaps == 1) {
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-          x[u][j] = *(const f32x4 *)(Xc + (((size_t)mtc[j] * a.XF + kf + u) * 64 + lane) * 4);
       } else {
+        // ONE load site per fragment, behind a pointer select: loads inside divergent-looking branches make the
+        // s_waitcnt insertion merge the paths conservatively and serialise the prefetch (see attn_kernel)
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-          const int ts = tin[j] * a.xstride + tap - halo;
-          const float *src = Xc;
-          long rr = (long)bT[j] * a.xstride + ts;
-          if (ts < 0) {
-            if (a.halo_mode == 0) { src = Xp; rr += (long)a.T * a.xstride; }
-            else if (a.halo_mode == 2) rr = (long)bT[j] * a.xstride;
+          const float *ptr;
+          if (a.ntaps == 1) {
+            ptr = Xc + (((size_t)mtc[j] * a.XF + kf + u) * 64 + lane) * 4;
+          } else {
+            const int ts = tin[j] * a.xstride + tap - halo;
+            const float *src = Xc;
+            long rr = (long)bT[j] * a.xstride + ts;
+            if (ts < 0) {
+              if (a.halo_mode == 0) { src = Xp; rr += (long)a.T * a.xstride; }
+              else if (a.halo_mode == 2) rr = (long)bT[j] * a.xstride;
+            }
+            ptr = src + (((size_t)(rr >> 4) * a.XF + cf) * 64 + (lane & 48) + (rr & 15)) * 4;
+            if (ts < 0 && a.halo_mode == 1) ptr = a.zeros;
           }
-          const float *ptr = src + (((size_t)(rr >> 4) * a.XF + cf) * 64 + (lane & 48) + (rr & 15)) * 4;
-          if (ts < 0 && a.halo_mode == 1) ptr = a.zeros;
           x[u][j] = *(const f32x4 *)ptr;
         }
         if (++cf == a.CF) { cf = 0; ++tap; }
@@ -437,27 +440,26 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
   const std::integral_constant<int, 1> c1{};
   int kf = k0;
   const int nfull = (k1 - k0) / U;
-  if constexpr (WK > 1 && TN * TM <= 4 && TN == 1) {
-    // decode (K-split) configurations: a wave owns only a few chunks, so every load is issued up front
-    // with one register set (high occupancy = more bytes in flight per CU) instead of double-buffering
-    for (int c = 0; c < nfull; ++c) {
-      f32x4 wA[U][TN], xA[U][TM];
-      load_chunk(cU, kf, wA, xA);
-      compute_chunk(cU, kf, wA, xA);
-      kf += U;
-    }
-  } else if (nfull > 0) {
+  if (nfull > 0) {
+    // Two register sets: chunk c+1 is in flight while chunk c feeds the MFMAs.  The steady-state loop issues
+    // its prefetches unconditionally (the tail is peeled), so the wait counts stay exact.  A decode wave that
+    // owns several chunks of a long K (FFN2: 4) no longer pays one full HBM round trip per chunk.
     f32x4 wA[U][TN], xA[U][TM], wB[U][TN], xB[U][TM];
     load_chunk(cU, kf, wA, xA);
     int c = 0;
-    for (; c + 2 <= nfull; c += 2) {
+    for (; c + 2 < nfull; c += 2) {
       load_chunk(cU, kf + U, wB, xB);
       compute_chunk(cU, kf, wA, xA);
-      if (c + 2 < nfull) load_chunk(cU, kf + 2 * U, wA, xA);
+      load_chunk(cU, kf + 2 * U, wA, xA);
       compute_chunk(cU, kf + U, wB, xB);
       kf += 2 * U;
     }
-    if (c < nfull) {
+    if (c + 1 < nfull) {
+      load_chunk(cU, kf + U, wB, xB);
+      compute_chunk(cU, kf, wA, xA);
+      compute_chunk(cU, kf + U, wB, xB);
+      kf += 2 * U;
+    } else {
       compute_chunk(cU, kf, wA, xA);
       kf += U;
     }
@@ -1277,18 +1279,28 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
   // Three rotating register tiles: the K/V of the next TWO key tiles (16 KB per wave) are in flight while a tile's
   // scores, softmax and P.V run.  A decode step streams the whole cache once with ~4 waves per CU, so bytes in
   // flight per wave are what sets the achieved HBM rate.
+  // The prefetches are UNCONDITIONAL (tile index clamped to the last tile, whose lines are then L1/L2 hits): a
+  // load behind a branch makes the compiler's s_waitcnt insertion merge the two paths conservatively and wait for
+  // the newest loads as well, which silently serialises the whole pipeline (seen in the ISA: vmcnt(5)..vmcnt(0)
+  // in front of the first MFMAs of a tile).
   f32x4 k0[4], v0[4], k1[4], v1[4], k2[4], v2[4];
-  if (ts < te) load_tile(ts, k0, v0);
-  if (ts + 1 < te) load_tile(ts + 1, k1, v1);
-  for (int tile = ts; tile < te; tile += 3) {
-    if (tile + 2 < te) load_tile(tile + 2, k2, v2);
-    process(tile, k0, v0);
-    if (tile + 1 >= te) break;
-    if (tile + 3 < te) load_tile(tile + 3, k0, v0);
-    process(tile + 1, k1, v1);
-    if (tile + 2 >= te) break;
-    if (tile + 4 < te) load_tile(tile + 4, k1, v1);
-    process(tile + 2, k2, v2);
+  if (ts < te) {
+    const int tl = te - 1;
+    load_tile(ts, k0, v0);
+    load_tile(min(ts + 1, tl), k1, v1);
+    int tile = ts;
+    // whole groups of three tiles: one back-edge, no exits from inside the body (every extra control-flow join
+    // makes the wait counts more conservative)
+    for (; tile + 3 <= te; tile += 3) {
+      load_tile(min(tile + 2, tl), k2, v2);
+      process(tile, k0, v0);
+      load_tile(min(tile + 3, tl), k0, v0);
+      process(tile + 1, k1, v1);
+      load_tile(min(tile + 4, tl), k1, v1);
+      process(tile + 2, k2, v2);
+    }
+    if (tile < te) process(tile, k0, v0);
+    if (tile + 1 < te) process(tile + 1, k1, v1);
   }
 
   if (a.splits == 1) {
@@ -1308,6 +1320,100 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
     if (g == 0) {
       pp[c * ATT_PSTRIDE + 64] = m_run;
       pp[c * ATT_PSTRIDE + 65] = l_run;
+    }
+  }
+}
+
+// Decode-step attention (ONE query per sequence): the same tiles, loads, masks, online softmax, split partials and
+// output layout as attn_kernel, but on the vector ALU with wavefront reductions.  A single query would use one of
+// the 16 MFMA columns; here a 16-key tile costs ~32 FMAs and a dozen cross-lane moves per lane, so the kernel is
+// bound by the KV stream (reference transformer.py:135-158 with T = 1).
+//   scores : lane (c = key, g) holds K[key c][16 df + 4g ..+3] (df = 0..3), dot with q, xor-reduce over g
+//   values : lane (c, g) holds V[key 4g + r][4c ..+3] (r = 0..3), o[4c..] += p[key] * V, xor-reduce over g at the end
+__global__ __launch_bounds__(64) void attn_decode_kernel(AttnArgs a) {
+  const int bh = blockIdx.x, sp = blockIdx.z;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+  const int pq = a.offset[b];  // position of the query; keys klo .. pq
+  const int klo = a.ctx > 0 ? max(0, pq - a.ctx + 1) : 0;
+  const int tile_lo = klo >> 4, tile_hi = (pq + 16) >> 4;
+  const int per = (tile_hi - tile_lo + a.splits - 1) / a.splits;
+  const int ts = tile_lo + sp * per;
+  const int te = min(tile_hi, ts + per);
+
+  f32x4 qv[4];  // q[16 df + 4g + j] * 1/sqrt(64): query row 0 of the block sits in lanes 16 g
+#pragma unroll
+  for (int df = 0; df < 4; ++df)
+    qv[df] = *(const f32x4 *)(a.Q + ((((size_t)bh * a.QB) * 4 + df) * 64 + 16 * g) * 4) * 0.125f;
+  const float *Kb = a.Kc + (size_t)bh * a.cap * 64;
+  const float *Vb = a.Vc + (size_t)bh * a.cap * 64;
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  float m_run = NEG_BIG, l_run = 0.f;
+
+  auto load_tile = [&](int tile, f32x4 *kk, f32x4 *vv) {
+    const int p0 = tile * 16;
+    const int slot0 = a.ring ? (p0 % a.ring) : p0;
+#pragma unroll
+    for (int df = 0; df < 4; ++df) kk[df] = *(const f32x4 *)(Kb + (size_t)(slot0 + c) * 64 + 16 * df + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vv[r] = *(const f32x4 *)(Vb + (size_t)(slot0 + 4 * g + r) * 64 + 4 * c);
+  };
+  auto process = [&](int tile, const f32x4 *kk, const f32x4 *vv) {
+    float s = 0.f;
+#pragma unroll
+    for (int df = 0; df < 4; ++df)
+      s += (kk[df].x * qv[df].x + kk[df].y * qv[df].y) + (kk[df].z * qv[df].z + kk[df].w * qv[df].w);
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);  // score of key tile*16 + c, in all four lanes of column c
+    const int pk = tile * 16 + c;
+    const bool ok = (pk <= pq) && (a.ctx <= 0 || pq - pk < a.ctx);
+    float mx = ok ? s : NEG_BIG;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = expf(m_run - m_new);
+    const float p = ok ? expf(s - m_new) : 0.f;
+    float ps = p;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) ps += __shfl_xor(ps, d);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+    o *= alpha;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o += vv[r] * __shfl(p, 4 * g + r);  // p of key 4g + r lives in lane 4g + r
+  };
+  f32x4 k0[4], v0[4], k1[4], v1[4], k2[4], v2[4];
+  if (ts < te) {  // same branch-free 2-deep prefetch as attn_kernel
+    const int tl = te - 1;
+    load_tile(ts, k0, v0);
+    load_tile(min(ts + 1, tl), k1, v1);
+    int tile = ts;
+    for (; tile + 3 <= te; tile += 3) {
+      load_tile(min(tile + 2, tl), k2, v2);
+      process(tile, k0, v0);
+      load_tile(min(tile + 3, tl), k0, v0);
+      process(tile + 1, k1, v1);
+      load_tile(min(tile + 4, tl), k1, v1);
+      process(tile + 2, k2, v2);
+    }
+    if (tile < te) process(tile, k0, v0);
+    if (tile + 1 < te) process(tile + 1, k1, v1);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    o[j] += __shfl_xor(o[j], 16);
+    o[j] += __shfl_xor(o[j], 32);
+  }
+  if (g != 0) return;
+  if (a.splits == 1) {
+    const size_t m = (size_t)b * a.Tq;
+    *(f32x4 *)(a.Y + (((m >> 4) * a.YF + 4 * h + (c >> 2)) * 64 + 16 * (c & 3) + (m & 15)) * 4) = o * (1.0f / l_run);
+  } else {
+    float *pp = a.part + (((size_t)bh * a.QB) * a.splits + sp) * 16 * ATT_PSTRIDE;  // row 0 of the block
+    *(f32x4 *)(pp + 4 * c) = o;
+    if (c == 0) {
+      pp[64] = m_run;
+      pp[65] = l_run;
     }
   }
 }
