@@ -171,7 +171,13 @@ struct ptts_graph {
 static hipStream_t g_alloc_stream = nullptr;
 static int dalloc(ptts_engine *e, void **p, size_t bytes) {
   if (bytes == 0) bytes = 256;
-  HIPCHK(hipMalloc(p, bytes));
+  *p = nullptr;
+  const hipError_t err = hipMalloc(p, bytes);
+  if (err != hipSuccess) {
+    (void)hipGetLastError();  // the error is reported here; do not leave it sticky for the next hipGetLastError()
+    *p = nullptr;
+    return fail(-2, "hipMalloc of " + std::to_string(bytes) + " bytes: " + hipGetErrorString(err));
+  }
   HIPCHK(hipMemsetAsync(*p, 0, bytes, g_alloc_stream));
   if (e) e->allocs.push_back(*p);
   return 0;
@@ -658,6 +664,8 @@ static int seanet_check(const ptts_config &c) {
   return 0;
 }
 
+static int build_engine(ptts_engine *e, const ptts_tensor *tensors, int32_t n);
+
 extern "C" int ptts_create(const ptts_config *cfg, const ptts_tensor *tensors, int32_t n, int32_t device,
                            ptts_engine **out) {
   return ptts_create_ex(cfg, tensors, n, device, 0, out);
@@ -674,6 +682,17 @@ extern "C" int ptts_create_ex(const ptts_config *cfg, const ptts_tensor *tensors
   e->device = device;
   e->tuner = new Tuner();
   e->quant_flags = quant_flags;
+  const int rc = build_engine(e, tensors, n);
+  if (rc < 0) {  // missing / ill-shaped tensor, HIP error: release what was built so far
+    const std::string msg = g_err;
+    ptts_destroy(e);
+    return fail(rc, msg);
+  }
+  *out = e;
+  return 0;
+}
+
+static int build_engine(ptts_engine *e, const ptts_tensor *tensors, int32_t n) {
   HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   g_alloc_stream = e->stream;
   HIPCHK(hipEventCreate(&e->ev0));
@@ -787,7 +806,6 @@ extern "C" int ptts_create_ex(const ptts_config *cfg, const ptts_tensor *tensors
   for (int i = 0; i < 3; ++i) e->mimi_bytes += e->convtr[i].bytes() + e->res_a[i].bytes() + e->res_b[i].bytes();
   HIPCHK(hipStreamSynchronize(e->stream));
   e->tmap.clear();
-  *out = e;
   return 0;
 }
 
@@ -859,16 +877,30 @@ static void free_scratch(Scratch *s) {
   *s = Scratch();
 }
 
+static int build_lm_state(ptts_engine *e, ptts_lm_state *s);
+
 extern "C" int ptts_lm_state_create(ptts_engine *e, int32_t B, int32_t t_cap, ptts_lm_state **out) {
-  if (!e || B < 1 || t_cap < 1) return fail(-1, "bad argument");
+  if (!e || !out || B < 1 || t_cap < 1) return fail(-1, "bad argument");
   HIPCHK(hipSetDevice(e->device));
-  const ptts_config &c = e->cfg;
-  g_alloc_stream = e->stream;
   ptts_lm_state *s = new ptts_lm_state();
   s->e = e;
   s->B = B;
   s->cap = cdiv(t_cap, 16) * 16;
   s->MT = cdiv(B, 16);
+  const int rc = build_lm_state(e, s);
+  if (rc < 0) {  // typically out of device memory for the KV cache: free the partial state
+    const std::string msg = g_err;
+    ptts_lm_state_destroy(s);
+    return fail(rc, msg);
+  }
+  *out = s;
+  return 0;
+}
+
+static int build_lm_state(ptts_engine *e, ptts_lm_state *s) {
+  const ptts_config &c = e->cfg;
+  const int B = s->B;
+  g_alloc_stream = e->stream;
   CHK(dallocT(nullptr, &s->kv, (size_t)c.num_layers * 2 * s->kv_plane()));
   CHK(dallocT(nullptr, &s->offset, B));
   s->h_off.assign(B, 0);
@@ -893,7 +925,6 @@ extern "C" int ptts_lm_state_create(ptts_engine *e, int32_t B, int32_t t_cap, pt
   set_int_kernel<<<cdiv(B, 256), 256, 0, e->stream>>>(s->active, B, 1);
   fill_kernel<<<cdiv(B * c.ldim, 256), 256, 0, e->stream>>>(s->lat_prev, (long)B * c.ldim, NAN);
   HIPCHK(hipStreamSynchronize(e->stream));
-  *out = s;
   return 0;
 }
 
@@ -1209,14 +1240,28 @@ extern "C" int ptts_lm_decode_step(ptts_engine *e, ptts_lm_state *s, const float
 
 // ------------------------------------------------------------------------------------------------
 // Mimi
+static int build_mimi_state(ptts_engine *e, ptts_mimi_state *s);
+
 extern "C" int ptts_mimi_state_create(ptts_engine *e, int32_t B, ptts_mimi_state **out) {
-  if (!e || B < 1) return fail(-1, "bad argument");
+  if (!e || !out || B < 1) return fail(-1, "bad argument");
   HIPCHK(hipSetDevice(e->device));
-  const ptts_config &c = e->cfg;
-  g_alloc_stream = e->stream;
   ptts_mimi_state *s = new ptts_mimi_state();
   s->e = e;
   s->B = B;
+  const int rc = build_mimi_state(e, s);
+  if (rc < 0) {
+    const std::string msg = g_err;
+    ptts_mimi_state_destroy(s);
+    return fail(rc, msg);
+  }
+  *out = s;
+  return 0;
+}
+
+static int build_mimi_state(ptts_engine *e, ptts_mimi_state *s) {
+  const ptts_config &c = e->cfg;
+  const int B = s->B;
+  g_alloc_stream = e->stream;
   s->MTb = cdiv(B, 16);
   s->MT16 = B;  // one 16-row tile per sequence
   const int C = c.m_dim, CF = C / 16;
@@ -1257,7 +1302,6 @@ extern "C" int ptts_mimi_state_create(ptts_engine *e, int32_t B, ptts_mimi_state
   }
   CHK(dallocT(nullptr, &s->pcm_dbg, (size_t)B * rows));
   HIPCHK(hipStreamSynchronize(e->stream));
-  *out = s;
   return 0;
 }
 

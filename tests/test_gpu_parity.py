@@ -353,3 +353,29 @@ def test_tuned_table_export_import_roundtrip(tmp_path, monkeypatch):
     eng.lib.ptts_tune_export(eng.handle, buf, len(buf))
     assert buf.value.decode() == table1
     assert eng.lib.ptts_tune_import(eng.handle, b"garbage line\n1 2 3\n") == 0
+
+
+def test_failed_creation_releases_and_reports():
+    """C-ABI failure paths: an engine built from an incomplete checkpoint and a KV cache that cannot be allocated
+    return an error code + message and leave nothing behind (the next creation succeeds)."""
+    import ctypes as C
+
+    from pocket_tts_amd import _lib
+    from pocket_tts_amd.engine import make_ptts_config
+
+    eng = get_engine("tiny")
+    lib = eng.lib
+    pc = make_ptts_config(eng.cfg)
+    arr = (_lib.PttsTensor * 1)()
+    dummy = torch.zeros(16, device="cuda:0")
+    arr[0].name = b"not.a.model.tensor"
+    arr[0].d_data = dummy.data_ptr()
+    arr[0].numel = 16
+    h = C.c_void_p()
+    rc = lib.ptts_create_ex(C.byref(pc), arr, 1, 0, 0, C.byref(h))
+    assert rc == -3 and not h.value and b"bos_emb" in lib.ptts_last_error()
+    assert lib.ptts_create_ex(C.byref(pc), arr, 1, 0, 64, C.byref(h)) == -1  # unknown quantisation group
+    with pytest.raises((RuntimeError, ValueError, MemoryError)):
+        eng.new_lm_state(64, 200_000_000)  # ~10^15 bytes of KV
+    st = eng.new_lm_state(2, 32)  # still healthy
+    st.close()
