@@ -570,16 +570,6 @@ static GemmArgs mk_gemm(const Lin &L, const float *X, int XF, int MT, int M) {
   return a;
 }
 
-static void launch_ln(hipStream_t st, const float *X, long xds, int XF, float *Y, int YF, const float *w,
-                      const float *b, const float *shift, const float *scale, int SF, int KF, float eps, int MT,
-                      const int *par) {
-  LnArgs a;
-  a.X = X; a.Xdstride = xds; a.XF = XF; a.Y = Y; a.YF = YF; a.w = w; a.b = b;
-  a.shift = shift; a.scale = scale; a.SF = SF; a.KF = KF; a.eps = eps; a.par = par;
-  ProfScope ps(st, "layernorm", 8.0 * MT * 16 * KF * 16, 0);
-  layernorm_kernel<<<MT, 256, 0, st>>>(a);
-}
-
 static int attn_wave_target() {
   static int t = [] { const char *v = getenv("PTTS_ATTN_WAVES"); return v ? atoi(v) : 1024; }();
   return t;

@@ -1032,96 +1032,6 @@ __global__ void fill_kernel(float *p, long n, float v) {
   if (i < n) p[i] = v;
 }
 
-// ---------------------------------------------------------------------------------------------
-// LayerNorm over K of an FM tensor (biased variance), optional affine and AdaLN modulate
-// (reference nn.LayerNorm eps 1e-5: mimi_transformer.py:26-27; flow MLP LayerNorm eps 1e-6 +
-// modulate: mlp.py:16-17,49-55,109).  One 256-thread block per 16-row tile; wave w owns KF/4 fragments
-// in registers, two-pass mean / variance, cross-wave reduction through LDS.
-// ---------------------------------------------------------------------------------------------
-struct LnArgs {
-  const float *X;
-  long Xdstride;
-  int XF;
-  float *Y;
-  int YF;
-  const float *w, *b;        // [K] or null
-  const float *shift, *scale;  // FM views (row stride SF) or null
-  int SF;
-  int KF;
-  float eps;
-  const int *par;
-};
-
-__global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
-  const int mt = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int par = a.par ? (*a.par & 1) : 0;
-  const float *X = a.X + par * a.Xdstride;
-  const int k0 = (a.KF * wave) / 4, k1 = (a.KF * (wave + 1)) / 4;
-  f32x4 v[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    int kf = k0 + i;
-    if (kf < k1) v[i] = *(const f32x4 *)(X + (((size_t)mt * a.XF + kf) * 64 + lane) * 4);
-  }
-  // the gains / biases are cold in cache once per step: issue their loads together with the data
-  f32x4 wv[16], bv[16];
-  if (a.w) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      int kf = k0 + i;
-      if (kf < k1) {
-        const int k = 16 * kf + 4 * (lane >> 4);
-        wv[i] = *(const f32x4 *)(a.w + k);
-        bv[i] = *(const f32x4 *)(a.b + k);
-      }
-    }
-  }
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    int kf = k0 + i;
-    if (kf < k1) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-  }
-  __shared__ float red[2][4][16];
-  s += __shfl_xor(s, 16);
-  s += __shfl_xor(s, 32);
-  if (lane < 16) red[0][wave][lane] = s;
-  __syncthreads();
-  const int ml = lane & 15;
-  const float K = (float)(a.KF * 16);
-  const float mean = (red[0][0][ml] + red[0][1][ml] + red[0][2][ml] + red[0][3][ml]) / K;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    int kf = k0 + i;
-    if (kf < k1) {
-      f32x4 d = v[i] - mean;
-      q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
-    }
-  }
-  q += __shfl_xor(q, 16);
-  q += __shfl_xor(q, 32);
-  if (lane < 16) red[1][wave][lane] = q;
-  __syncthreads();
-  const float var = (red[1][0][ml] + red[1][1][ml] + red[1][2][ml] + red[1][3][ml]) / K;
-  const float rstd = 1.0f / sqrtf(var + a.eps);
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    int kf = k0 + i;
-    if (kf < k1) {
-      f32x4 y = (v[i] - mean) * rstd;
-      if (a.w) y = y * wv[i] + bv[i];
-      if (a.scale) {
-        f32x4 sc = *(const f32x4 *)(a.scale + (((size_t)mt * a.SF + kf) * 64 + lane) * 4);
-        f32x4 sh = *(const f32x4 *)(a.shift + (((size_t)mt * a.SF + kf) * 64 + lane) * 4);
-        y = y * (1.0f + sc) + sh;
-      }
-      *(f32x4 *)(a.Y + (((size_t)mt * a.YF + kf) * 64 + lane) * 4) = y;
-    }
-  }
-}
-
 // The flow MLP's variance-based "RMSNorm" on one row + average of the two time embeddings
 // (reference mlp.py:20-25,70,204-206).  Load-time constant folding, one wave.
 __global__ void tcomb_kernel(const float *h0_fm, const float *h1_fm, const float *alpha0, const float *alpha1,

@@ -163,28 +163,6 @@ static void test_gemm_lnfold(int M, int N, int K, int cfg) {
   report(nm, maxerr(g2, Y), 2e-4 * std::sqrt((double)K / 64));
 }
 
-static void test_ln(int M, int K) {
-  std::vector<float> X(M * K), w(K), b(K), Y(M * K);
-  for (auto &v : X) v = frand() * 3 + 0.5f; for (auto &v : w) v = 1 + 0.1f * frand(); for (auto &v : b) v = 0.1f * frand();
-  for (int m = 0; m < M; ++m) {
-    double mu = 0, var = 0; for (int k = 0; k < K; ++k) mu += X[m * K + k]; mu /= K;
-    for (int k = 0; k < K; ++k) var += (X[m * K + k] - mu) * (X[m * K + k] - mu); var /= K;
-    for (int k = 0; k < K; ++k) Y[m * K + k] = (float)((X[m * K + k] - mu) / std::sqrt(var + 1e-5) * w[k] + b[k]);
-  }
-  int MT = cdiv(M, 16), KF = K / 16;
-  float *dX = dev(X), *dw = dev(w), *db = dev(b);
-  float *xfm = dzero<float>((size_t)MT * KF * 256), *yfm = dzero<float>((size_t)MT * KF * 256), *dY = dzero<float>((size_t)M * K);
-  to_fm_kernel<<<cdiv((long)MT * KF * 64, 256), 256>>>(dX, xfm, M, K, MT);
-  LnArgs a; memset(&a, 0, sizeof a);
-  a.X = xfm; a.XF = KF; a.Y = yfm; a.YF = KF; a.w = dw; a.b = db; a.KF = KF; a.eps = 1e-5f;
-  layernorm_kernel<<<MT, 256>>>(a);
-  from_fm_kernel<<<cdiv((long)M * K / 4, 256), 256>>>(yfm, dY, M, K, KF, 0);
-  CK(hipDeviceSynchronize());
-  char nm[128]; snprintf(nm, sizeof nm, "layernorm M=%d K=%d", M, K);
-  report(nm, maxerr(host(dY, (size_t)M * K), Y), 1e-4);
-}
-
-// attention: B*H heads, Tq new tokens appended at offset `off`, optional window / ring
 static void test_attn(int BH, int Tq, int off, int ctx, int ring, int splits) {
   const int H = 2; int B = BH / H;
   int T = off + Tq, cap = ring ? ring : cdiv(T, 16) * 16, QB = cdiv(Tq, 16);
@@ -242,7 +220,6 @@ int main() {
   test_conv(5, 48, 32, 70, 2, 3);
   test_conv(4, 96, 16, 1, 3, 5);
   test_conv(5, 48, 32, 70, 2, 100); test_conv(3, 32, 64, 96, 3, 101); test_conv(9, 16, 32, 64, 7, 100);
-  test_ln(5, 128); test_ln(40, 512); test_ln(16, 1024);
   test_gemm_lnfold(3, 48, 128, 0); test_gemm_lnfold(50, 96, 1024, 2); test_gemm_lnfold(200, 130, 512, 3);
   test_gemm_lnfold(130, 64, 1024, 7);
   test_attn(4, 1, 0, 0, 0, 1);
