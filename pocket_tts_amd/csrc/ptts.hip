@@ -1098,11 +1098,11 @@ extern "C" int64_t ptts_profile_stop(ptts_engine *e, char *h_out, int64_t capaci
   return (int64_t)out.size();
 }
 
-static void lm_layers(hipStream_t st, ptts_engine *e, ptts_lm_state *s, Scratch &sc, int M, int Tq) {
+static void lm_layers(hipStream_t st, ptts_engine *e, ptts_lm_state *s, Scratch &sc, int M, int Tq, bool rope_done = false) {
   const ptts_config &c = e->cfg;
   bind_engine(e);
-  SITE("lm.rope");
-  {
+  if (!rope_done) {  // decode steps build the table in their prologue kernel
+    SITE("lm.rope");
     ProfScope ps(st, "rope_table", 256.0 * M, 0);
     rope_table_kernel<<<cdiv(M * 32, 256), 256, 0, st>>>(s->offset, e->freq_lm, sc.rope, M, Tq);
   }
@@ -1158,15 +1158,17 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
   SITE("lm.prep");
   {
     ProfScope ps(st, "prep_lm", 16.0 * B * c.ldim, 0);
-    prep_lm_kernel<<<cdiv(MT * LF * 64, 256), 256, 0, st>>>(d_latent_in ? d_latent_in : s->lat_prev, e->bos, d_noise,
-                                                             s->xlat, s->lat, s->latfm, B, c.ldim, MT, s->rng_std,
-                                                             s->rng_seed, s->rng_ctr);
+    const int nb_prep = cdiv(MT * LF * 64, 256);
+    prep_lm_kernel<<<nb_prep + cdiv(B * 32, 256), 256, 0, st>>>(d_latent_in ? d_latent_in : s->lat_prev, e->bos, d_noise,
+                                                                 s->xlat, s->lat, s->latfm, B, c.ldim, MT, s->rng_std,
+                                                                 s->rng_seed, s->rng_ctr, nb_prep,
+                                                                 RopeArgs{s->offset, e->freq_lm, sc.rope, B, 1});
   }
   SITE("lm.in_linear");
   GemmArgs a = mk_gemm(e->in_linear, s->xlat, LF, MT, B);
   a.Y = sc.x; a.YF = DF;
   launch_gemm(st, a, PRE_NONE);
-  lm_layers(st, e, s, sc, B, 1);
+  lm_layers(st, e, s, sc, B, 1, true);
   SITE("flow.head");  // out_norm is folded into [cond_embed ; out_eos]
   a = mk_gemm(e->head, sc.x, DF, MT, B);
   a.epi = EPI_HEAD; a.Y = s->ce; a.YF = FDF; a.head_nt = FDF; a.eos_thr = eos_thr;
@@ -1363,7 +1365,9 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
   SITE("mimi.prep");
   {
     ProfScope ps(st, "prep_mimi", 8.0 * B * c.ldim, 0);
-    prep_mimi_kernel<<<cdiv(s->MTb * LF * 64, 256), 256, 0, st>>>(d_latent, e->emb_std, e->emb_mean, s->zl, B, c.ldim, s->MTb);
+    const int nb_prep = cdiv(s->MTb * LF * 64, 256);
+    prep_mimi_kernel<<<nb_prep + cdiv(B * st16 * 32, 256), 256, 0, st>>>(d_latent, e->emb_std, e->emb_mean, s->zl, B, c.ldim, s->MTb, nb_prep,
+                                                                          RopeArgs{s->offset, e->freq_mimi, s->rope, B * st16, st16});
   }
   SITE("mimi.quant");
   GemmArgs a = mk_gemm(e->quant, s->zl, LF, s->MTb, B);
@@ -1376,11 +1380,7 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
     upsample_kernel<<<cdiv(tot, 256), 256, 0, st>>>(s->zq, s->zq_stride, s->frame, e->up_w, s->u0, B, C, st16);
   }
   const int M16 = B * st16;
-  SITE("mimi.rope");
-  {
-    ProfScope ps(st, "rope_table", 256.0 * M16, 0);
-    rope_table_kernel<<<cdiv(M16 * 32, 256), 256, 0, st>>>(s->offset, e->freq_mimi, s->rope, M16, st16);
-  }
+
   for (int l = 0; l < c.m_layers; ++l) {
     TrCtx t;
     t.D = C; t.H = c.m_heads; t.FF = c.m_ff; t.MT = s->MT16; t.M = M16; t.Tq = st16; t.QB = 1;

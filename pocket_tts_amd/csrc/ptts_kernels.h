@@ -902,9 +902,33 @@ __device__ __forceinline__ float counter_normal(unsigned long long seed, unsigne
   return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
 
+// cos / sin of (offset[b] + t) * freq[i] for every row m = b*Tq + t, i < 32 (reference rope.py:28-50):
+// computed once per step instead of once per (layer, n-tile) in the QKV epilogue
+struct RopeArgs {
+  const int *offset;
+  const float *freq;
+  float *tab;
+  int M, Tq;
+};
+__device__ __forceinline__ void rope_table_entry(const RopeArgs &r, int i) {
+  if (i >= r.M * 32) return;
+  int m = i >> 5, f = i & 31;
+  int b = m / r.Tq, t = m - b * r.Tq;
+  float sn, cs;
+  sincosf(r.freq[f] * (float)(r.offset[b] + t), &sn, &cs);
+  r.tab[2 * i] = cs;
+  r.tab[2 * i + 1] = sn;
+}
+
+// Step prologue of the FlowLM: BOS substitution + noise + FM conversion of the input latent (blocks < nb_prep) and the
+// step's RoPE table (the remaining blocks): one launch instead of two.
 __global__ void prep_lm_kernel(const float *lat_in, const float *bos, const float *noise, float *x_fm, float *lat,
                                float *lat_fm, int B, int ldim, int MT, float rng_std, unsigned long long rng_seed,
-                               const int *rng_ctr) {
+                               const int *rng_ctr, int nb_prep, RopeArgs rope) {
+  if ((int)blockIdx.x >= nb_prep) {
+    rope_table_entry(rope, (blockIdx.x - nb_prep) * blockDim.x + threadIdx.x);
+    return;
+  }
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int KF = ldim / 16;
   if (i >= MT * KF * 64) return;
@@ -938,7 +962,11 @@ __global__ void prep_lm_kernel(const float *lat_in, const float *bos, const floa
 
 // Mimi input: latent * emb_std + emb_mean (reference tts_model.py:449) to FM
 __global__ void prep_mimi_kernel(const float *lat, const float *std, const float *mean, float *z_fm, int B, int ldim,
-                                 int MT) {
+                                 int MT, int nb_prep, RopeArgs rope) {
+  if ((int)blockIdx.x >= nb_prep) {  // the frame's RoPE table rides along (see prep_lm_kernel)
+    rope_table_entry(rope, (blockIdx.x - nb_prep) * blockDim.x + threadIdx.x);
+    return;
+  }
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int KF = ldim / 16;
   if (i >= MT * KF * 64) return;
@@ -980,17 +1008,8 @@ __global__ void upsample_kernel(const float *zq, long zdstride, const int *par_p
   *(f32x4 *)(out + (((size_t)(m >> 4) * CF + (c >> 4)) * 64 + 16 * ((c & 15) >> 2) + (m & 15)) * 4) = o;
 }
 
-// cos / sin of (offset[b] + t) * freq[i] for every row m = b*Tq + t, i < 32 (reference rope.py:28-50):
-// computed once per step instead of once per (layer, n-tile) in the QKV epilogue
 __global__ void rope_table_kernel(const int *offset, const float *freq, float *tab, int M, int Tq) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M * 32) return;
-  int m = i >> 5, f = i & 31;
-  int b = m / Tq, t = m - b * Tq;
-  float sn, cs;
-  sincosf(freq[f] * (float)(offset[b] + t), &sn, &cs);
-  tab[2 * i] = cs;
-  tab[2 * i + 1] = sn;
+  rope_table_entry(RopeArgs{offset, freq, tab, M, Tq}, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // mono audio [T] -> FM rows of 16 channels (channel 0 = sample, the rest zero) for the encoder's first conv
