@@ -28,6 +28,20 @@ from .text import estimate_max_gen_len, prepare_text_prompt, split_into_best_sen
 logger = logging.getLogger(__name__)
 
 
+def eos_bookkeeping(local_step: int, max_gen_len: int, frames_after_eos: int, eos_step, flag: bool):
+    """Per-row restatement of the reference's generation loop (tts_model.py:756-775), evaluated after FlowLM step
+    `local_step` (0-based) of an utterance: returns `(eos_step, n_emit)`.  `n_emit` is None while the row keeps
+    running; otherwise it is the number of frames the utterance consists of: the latent of the step at which the
+    reference's loop breaks is NOT decoded, and without EOS the row stops after `max_gen_len` frames."""
+    if local_step >= max_gen_len:
+        return eos_step, max_gen_len
+    if flag and eos_step is None:
+        eos_step = local_step
+    if eos_step is not None and local_step >= eos_step + frames_after_eos:
+        return eos_step, local_step
+    return eos_step, None
+
+
 class Request:
     """One submitted text.  Iterate to receive chunks; `result()` waits for the whole waveform."""
 
@@ -211,19 +225,10 @@ class ContinuousBatcher:
         for b, job in enumerate(self.slot):
             if job is None:
                 continue
-            local = g - job.start
-            leave = False
-            if local >= job.gen:
-                job.n_emit = job.gen  # maximum length without EOS (tts_model.py:770-775)
-                logger.warning("Maximum generation length reached without EOS, this very often indicates an error.")
-                leave = True
-            else:
-                if bool(flags[b].item()) and job.eos_step is None:
-                    job.eos_step = local
-                if job.eos_step is not None and local >= job.eos_step + job.fae:
-                    job.n_emit = local  # the break-step latent is not decoded (tts_model.py:763-764)
-                    leave = True
-            if leave:
+            job.eos_step, job.n_emit = eos_bookkeeping(g - job.start, job.gen, job.fae, job.eos_step, bool(flags[b].item()))
+            if job.n_emit is not None:
+                if job.eos_step is None:
+                    logger.warning("Maximum generation length reached without EOS, this very often indicates an error.")
                 self.st.set_row_active(b, False)
                 self.slot[b] = None
         pipe.decode_async(g)

@@ -206,6 +206,7 @@ class TTSModel:
         temp == 0 each waveform equals the single-utterance result; with temp > 0 rows draw independent noise
         (the reference's sequential use of the global generator cannot be reproduced across a batch).
         Returns a list of fp32 CPU tensors."""
+        from .batching import eos_bookkeeping
         from .engine import StepPipeline
 
         eng = self.engine
@@ -256,15 +257,8 @@ class TTSModel:
                 pipe.lm_step_async()
                 flags = pipe.wait_flags(step)
                 for b in range(B):
-                    if n_emit[b] is not None:
-                        continue
-                    if step >= gens[b]:
-                        n_emit[b] = gens[b]           # max length without EOS (warning path, tts_model.py:770-775)
-                        continue
-                    if bool(flags[b].item()) and eos_step[b] is None:
-                        eos_step[b] = step
-                    if eos_step[b] is not None and step >= eos_step[b] + faes[b]:
-                        n_emit[b] = step              # the break-step latent is not decoded
+                    if n_emit[b] is None:
+                        eos_step[b], n_emit[b] = eos_bookkeeping(step, gens[b], faes[b], eos_step[b], bool(flags[b].item()))
                 if all(n is not None and n <= step for n in n_emit):
                     break
                 # collect the previous frame before its pinned buffer is reused two frames later

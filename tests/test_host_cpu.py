@@ -58,3 +58,32 @@ def test_wav_writer(tmp_path):
         assert (w.getnchannels(), w.getframerate(), w.getsampwidth(), w.getnframes()) == (1, 24000, 2, n)
         x = np.frombuffer(w.readframes(n), dtype=np.int16)
     assert x[0] == 16383 and x[1920] == -32767 and np.all(x[-4800:] == 0)
+
+
+def test_eos_bookkeeping_matches_reference_loop():
+    """pocket_tts_amd.batching.eos_bookkeeping (per-row EOS / frame-count decision of the batched paths) against a
+    literal restatement of the reference's loop (tts_model.py:756-775) on random EOS flag sequences: the number of
+    latents the reference puts in its queue must equal n_emit, for every max_gen_len / frames_after_eos."""
+    import random
+
+    from pocket_tts_amd.batching import eos_bookkeeping as f  # importable without a GPU (the engine loads lazily)
+
+    def reference(flags, max_gen_len, fae):
+        put, eos_step = 0, None
+        for step in range(max_gen_len):
+            if flags[step] and eos_step is None:
+                eos_step = step
+            if eos_step is not None and step >= eos_step + fae:
+                break
+            put += 1
+        return put
+
+    rnd = random.Random(0)
+    for _ in range(2000):
+        n, fae = rnd.randint(1, 40), rnd.randint(0, 6)
+        flags = [rnd.random() < 0.08 for _ in range(n + 8)]
+        eos, n_emit, step = None, None, 0
+        while n_emit is None:
+            eos, n_emit = f(step, n, fae, eos, flags[step] if step < len(flags) else False)
+            step += 1
+        assert n_emit == reference(flags, n, fae), (flags, n, fae)
