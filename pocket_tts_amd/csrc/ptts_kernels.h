@@ -145,12 +145,20 @@ __device__ __forceinline__ f32x4 pre4(f32x4 x, const float *prevec, int kf, int 
   return x;
 }
 
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 acc, int nt, int mt, int lane, int par) {
+// Epilogue operands a wave can fetch at kernel START for the tiles it will finish (K-split path): bias, residual
+// and gate tiles, LN-fold vectors, int8 scales.  Loaded after the reduction they would add one dependent L2 round
+// trip (~0.6 us) to every decode GEMM.
+struct EpiPre {
+  f32x4 bias, r, g, ln_s, ln_c, scale;
+};
+
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 acc, int nt, int mt, int lane, int par,
+                                              const EpiPre *pf = nullptr) {
   const int ml = lane & 15, g = lane >> 4;
   const int m = 16 * mt + ml;
   const int n0 = 16 * nt + 4 * g;
   if (a.bias) {
-    f32x4 b = *(const f32x4 *)(a.bias + n0);
+    f32x4 b = pf ? pf->bias : *(const f32x4 *)(a.bias + n0);
     acc += b;
   }
   switch (a.epi) {
@@ -162,14 +170,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 acc, int 
     } break;
     case EPI_RES: {
       const float *r = a.R + par * a.Rdstride;
-      f32x4 rv = *(const f32x4 *)(r + (((size_t)mt * a.RF + nt) * 64 + lane) * 4);
+      f32x4 rv = pf ? pf->r : *(const f32x4 *)(r + (((size_t)mt * a.RF + nt) * 64 + lane) * 4);
       if (a.ls) acc *= *(const f32x4 *)(a.ls + n0);
       float *y = a.Y + par * a.Ydstride;
       *(f32x4 *)(y + (((size_t)mt * a.YF + nt) * 64 + lane) * 4) = act4(rv + acc, a.act);
     } break;
     case EPI_GATE: {
-      f32x4 rv = *(const f32x4 *)(a.R + (((size_t)mt * a.RF + nt) * 64 + lane) * 4);
-      f32x4 gv = *(const f32x4 *)(a.G + (((size_t)mt * a.GF + nt) * 64 + lane) * 4);
+      f32x4 rv = pf ? pf->r : *(const f32x4 *)(a.R + (((size_t)mt * a.RF + nt) * 64 + lane) * 4);
+      f32x4 gv = pf ? pf->g : *(const f32x4 *)(a.G + (((size_t)mt * a.GF + nt) * 64 + lane) * 4);
       *(f32x4 *)(a.Y + (((size_t)mt * a.YF + nt) * 64 + lane) * 4) = rv + gv * acc;
     } break;
     case EPI_QKV: {
@@ -323,6 +331,32 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
       const float invK = 1.0f / (float)(a.KF * 16);
       lmu[j] = s1 * invK;
       lrs[j] = 1.0f / sqrtf(fmaxf(s2 * invK - lmu[j] * lmu[j], 0.f) + a.ln_eps);
+    }
+  }
+  // K-split path: tile e of this wave (tile index wk + e * WK in i-major order) is finished by this wave; fetch its
+  // epilogue operands now (see EpiPre)
+  constexpr int EPT = (WK > 1) ? (TN * TM + WK - 1) / WK : 1;
+  EpiPre epf[EPT];
+  if constexpr (WK > 1) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int tl = wk + e * WK;
+      const int i = tl / TM, j = tl - i * TM;
+      const int nt = min(nt0 + i, a.NT - 1), mt = min(mt0 + j, a.MT - 1);
+      const int n0 = 16 * nt + 4 * (lane >> 4);
+      if (tl < TN * TM) {
+        if (a.bias) epf[e].bias = *(const f32x4 *)(a.bias + n0);
+        if constexpr (Q8) epf[e].scale = *(const f32x4 *)(a.wscale + n0);
+        if constexpr (PRE == PRE_LNFOLD) {
+          epf[e].ln_s = *(const f32x4 *)(a.ln_s + n0);
+          epf[e].ln_c = *(const f32x4 *)(a.ln_c + n0);
+        }
+        if (a.epi == EPI_RES) epf[e].r = *(const f32x4 *)(a.R + par * a.Rdstride + (((size_t)mt * a.RF + nt) * 64 + lane) * 4);
+        if (a.epi == EPI_GATE) {
+          epf[e].r = *(const f32x4 *)(a.R + (((size_t)mt * a.RF + nt) * 64 + lane) * 4);
+          epf[e].g = *(const f32x4 *)(a.G + (((size_t)mt * a.GF + nt) * 64 + lane) * 4);
+        }
+      }
     }
   }
   int tap = 0, cf = k0;
@@ -495,11 +529,11 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
       sxx[j] += __shfl_xor(sxx[j], 16); sxx[j] += __shfl_xor(sxx[j], 32);
     }
   }
-  auto ln_fix = [&](f32x4 v, int nt, int j) {
-    if constexpr (Q8) v *= *(const f32x4 *)(a.wscale + 16 * nt + 4 * (lane >> 4));
+  auto ln_fix = [&](f32x4 v, int nt, int j, const EpiPre *pf) {
+    if constexpr (Q8) v *= pf ? pf->scale : *(const f32x4 *)(a.wscale + 16 * nt + 4 * (lane >> 4));
     if constexpr (PRE == PRE_LNFOLD) {
       const int n0 = 16 * nt + 4 * (lane >> 4);
-      const f32x4 s4 = *(const f32x4 *)(a.ln_s + n0), c4 = *(const f32x4 *)(a.ln_c + n0);
+      const f32x4 s4 = pf ? pf->ln_s : *(const f32x4 *)(a.ln_s + n0), c4 = pf ? pf->ln_c : *(const f32x4 *)(a.ln_c + n0);
       return (v - s4 * mu[j]) * rs[j] + c4;
     } else {
       return v;
@@ -545,7 +579,8 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
         if ((i * TM + j) % WK != wk) continue;
         f32x4 sum = red[(((0 * WN * WM + grp) * TN + i) * TM + j) * 64 + lane];
         for (int s2 = 1; s2 < WK; ++s2) sum += red[(((s2 * WN * WM + grp) * TN + i) * TM + j) * 64 + lane];
-        if (nt0 + i < a.NT && mt0 + j < a.MT) gemm_epilogue(a, ln_fix(sum, nt0 + i, j), nt0 + i, mt0 + j, lane, par);
+        const EpiPre *pf = &epf[(i * TM + j) / WK];
+        if (nt0 + i < a.NT && mt0 + j < a.MT) gemm_epilogue(a, ln_fix(sum, nt0 + i, j, pf), nt0 + i, mt0 + j, lane, par, pf);
       }
   } else {
     if constexpr (PRE == PRE_LNFOLD) {
@@ -560,7 +595,7 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
     for (int i = 0; i < TN; ++i)
 #pragma unroll
       for (int j = 0; j < TM; ++j)
-        if (nt0 + i < a.NT && mt0 + j < a.MT) gemm_epilogue(a, ln_fix(accs[i][j], nt0 + i, j), nt0 + i, mt0 + j, lane, par);
+        if (nt0 + i < a.NT && mt0 + j < a.MT) gemm_epilogue(a, ln_fix(accs[i][j], nt0 + i, j, nullptr), nt0 + i, mt0 + j, lane, par);
   }
   (void)NW;
 }
