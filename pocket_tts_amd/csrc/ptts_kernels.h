@@ -369,7 +369,7 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
   // MFMAs of chunk c, into a second register set, so the matrix pipe works while the next operands fly.
   // decode (K-split) tiles: as many fragments per round as the register file allows, so that a wave needs
   // few serialized HBM round trips for its cold weight stream
-  constexpr int U0 = (TN * TM == 1) ? 8 : (TN * TM == 2 && WK > 1) ? 8 : (TN * TM <= 4 && WK >= 8) ? 8 : (TN * TM <= 4 && WK > 1) ? 4 : 2;
+  constexpr int U0 = (TN * TM == 1) ? 8 : (TN * TM == 2 && WK > 1) ? 8 : (TN * TM <= 4 && WK > 1) ? 4 : 2;
   constexpr int U = (Q8 && U0 < 4) ? 4 : U0;  // int8 weights arrive four k-fragments per load
   auto load_chunk = [&](auto uc, int kf, f32x4 (*w)[TN], f32x4 (*x)[TM]) {
     constexpr int UU = decltype(uc)::value;
