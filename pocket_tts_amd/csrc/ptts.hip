@@ -530,6 +530,25 @@ static void launch_gemm(hipStream_t st, const GemmArgs &a_in, int pre) {
     if (it != g_tuner->table.end()) cfg = it->second;
     else if (g_tuner->active) cfg = g_tuner->table[key] = tune_one(st, a, pre, *g_tuner);
   }
+  {
+    // PTTS_FORCE_CFG="NT:MT:cfg[,NT:MT:cfg...]": experiment knob, pins the configuration of one GEMM shape
+    static const std::vector<std::array<int, 3>> forced = [] {
+      std::vector<std::array<int, 3>> v;
+      if (const char *e = getenv("PTTS_FORCE_CFG")) {
+        std::array<int, 3> t;
+        const char *p = e;
+        while (sscanf(p, "%d:%d:%d", &t[0], &t[1], &t[2]) == 3) {
+          v.push_back(t);
+          while (*p && *p != ',') ++p;
+          if (!*p) break;
+          ++p;
+        }
+      }
+      return v;
+    }();
+    for (auto &f : forced)
+      if (f[0] == a.NT && f[1] == a.MT && f[2] >= 0 && f[2] < kNumCfg && cfg_valid(f[2], a, pre)) cfg = f[2];
+  }
   if (cfg < 0 || !cfg_valid(cfg, a, pre)) cfg = pick_cfg(a);
   if (a.Wq && !cfg_valid(cfg, a, pre)) cfg = 3;
   if (a.Wq) bytes -= 3.0 * N * K;  // one byte per weight
@@ -1795,6 +1814,9 @@ extern "C" int64_t ptts_debug_read(ptts_engine *e, void *state, int32_t is_mimi,
     if (n == "upsample") { src = s->u0; M = B * 16; K = c.m_dim; }
     else if (n == "dec_tr") { src = s->tr_out + par * s->tr_stride; M = B * 16; K = c.m_dim; }
     else if (n == "seanet0") { src = s->a0 + par * s->a0_stride; M = B * 16; K = 8 * c.n_filters; }
+    else if (n == "tr_attn") { src = s->ao; M = B * 16; K = c.m_dim; }       // last layer's attention output
+    else if (n == "tr_resid") { src = s->u; M = B * 16; K = c.m_dim; }       // last layer's stream after attention
+    else if (n == "tr_ff") { src = s->ff; M = B * 16; K = c.m_ff; }          // last layer's GELU(linear1)
     else if (n == "seanet11") {
       M = B; K = s->rows[3];
       if ((int64_t)M * K > capacity) return fail(-1, "capacity");

@@ -379,3 +379,45 @@ def test_failed_creation_releases_and_reports():
         eng.new_lm_state(64, 200_000_000)  # ~10^15 bytes of KV
     st = eng.new_lm_state(2, 32)  # still healthy
     st.close()
+
+
+def test_full_size_batch64_properties():
+    """BASELINE config #3 at full size (100M model, batch 64, voice 126 + text 32 positions) through properties that
+    need no oracle run: (a) 64 rows fed identical inputs produce identical latents / EOS logits / PCM (every row tile
+    and workgroup computes the same thing), (b) row 0 agrees with a batch-1 run of the same inputs (different tile
+    configurations, fp32 summation order only), (c) rows fed DIFFERENT inputs differ (no cross-row leakage is hidden
+    by (a)): permuting the rows of the input permutes the rows of the output."""
+    eng = get_engine("en100m")
+    rng = np.random.default_rng(21)
+    B, Tp, ns = 64, 126 + 32, 4
+    one = (rng.standard_normal((1, Tp, eng.D)) * 0.3).astype(np.float32)
+
+    def run(emb, tune):
+        b = emb.shape[0]
+        if tune:
+            eng.tune(b)
+        st, ms = eng.new_lm_state(b, Tp + ns + 1), eng.new_mimi_state(b)
+        eng.lm_prefill(st, dev(emb))
+        outs = []
+        for _ in range(ns):
+            o, lg, _ = eng.lm_decode_step(st, None, None, 1, -4.0)
+            p = eng.mimi_decode(ms, o)
+            torch.cuda.synchronize()
+            outs.append((o.cpu().numpy().copy(), lg.cpu().numpy().reshape(-1).copy(), p.cpu().numpy().copy()))
+        st.close(); ms.close()
+        return outs
+
+    same = run(np.repeat(one, B, axis=0), True)
+    single = run(one, True)
+    for (o, lg, p), (o1, lg1, p1) in zip(same, single):
+        assert np.array_equal(o, np.repeat(o[:1], B, axis=0)) and np.array_equal(p, np.repeat(p[:1], B, axis=0))
+        assert np.array_equal(lg, np.repeat(lg[:1], B))
+        assert _maxerr(o[0], o1[0]) < ATOL and _maxerr(p[0], p1[0]) < ATOL and _maxerr(lg[0], lg1[0]) < 1e-3
+    # (c) distinct rows + permutation equivariance
+    emb = (rng.standard_normal((B, Tp, eng.D)) * 0.3).astype(np.float32)
+    perm = rng.permutation(B)
+    a = run(emb, False)
+    b = run(emb[perm], False)
+    for (o, lg, p), (o2, lg2, p2) in zip(a, b):
+        assert np.abs(o[0] - o[1]).max() > 1e-3
+        assert np.array_equal(o[perm], o2) and np.array_equal(p[perm], p2) and np.array_equal(lg[perm], lg2)
