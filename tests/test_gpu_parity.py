@@ -421,3 +421,53 @@ def test_full_size_batch64_properties():
     for (o, lg, p), (o2, lg2, p2) in zip(a, b):
         assert np.abs(o[0] - o[1]).max() > 1e-3
         assert np.array_equal(o[perm], o2) and np.array_equal(p[perm], p2) and np.array_equal(lg[perm], lg2)
+
+
+def test_full_size_prefill_and_state_properties():
+    """100M model, full-size prompts: (a) prefilling a prompt in two parts equals prefilling it at once (the cache
+    holds the same keys / values: reference transformer.py:39-84 appends at `offset`), (b) a decode step equals a
+    one-token prefill of the same input latent's embedding position-wise (same KV row written), checked through the
+    KV cache, (c) a cloned state continues bit-identically to its source, and a row copied into another batch row
+    (continuous batching) continues like the batch-1 original to summation-order accuracy."""
+    eng = get_engine("en100m")
+    rng = np.random.default_rng(33)
+    T1, T2, B = 126, 32, 3
+    emb = (rng.standard_normal((B, T1 + T2, eng.D)) * 0.3).astype(np.float32)
+    whole = eng.new_lm_state(B, T1 + T2 + 8)
+    eng.lm_prefill(whole, dev(emb))
+    parts = eng.new_lm_state(B, T1 + T2 + 8)
+    eng.lm_prefill(parts, dev(emb[:, :T1]))
+    eng.lm_prefill(parts, dev(emb[:, T1:]))
+    assert list(parts.offsets()) == list(whole.offsets()) == [T1 + T2] * B
+    for layer in (0, eng.L - 1):
+        a = whole.export_layer(layer, T1 + T2).cpu().numpy()
+        b = parts.export_layer(layer, T1 + T2).cpu().numpy()
+        assert _maxerr(a, b) < ATOL, layer
+    # (c) clone continues identically (same batch size => same tiles => bitwise)
+    clone = eng.new_lm_state(B, T1 + T2 + 8)
+    clone.copy_from(whole)
+    outs = []
+    for st in (whole, clone):
+        seq = []
+        for _ in range(3):
+            o, lg, _ = eng.lm_decode_step(st, None, None, 1, -4.0)
+            torch.cuda.synchronize()
+            seq.append((o.cpu().numpy().copy(), lg.cpu().numpy().copy()))
+        outs.append(seq)
+    for (o1, l1), (o2, l2) in zip(*outs):
+        assert np.array_equal(o1, o2) and np.array_equal(l1, l2)
+    # a batch-1 state copied into row 2 of a 4-row batch whose other rows hold something else
+    one = eng.new_lm_state(1, T1 + T2 + 8)
+    eng.lm_prefill(one, dev(emb[1:2]))
+    big = eng.new_lm_state(4, T1 + T2 + 8)
+    eng.lm_prefill(big, dev((rng.standard_normal((4, 40, eng.D)) * 0.3).astype(np.float32)))
+    big.copy_row_from(2, one)
+    assert list(big.offsets()) == [40, 40, T1 + T2, 40]
+    for _ in range(3):
+        o1, l1, _ = eng.lm_decode_step(one, None, None, 1, -4.0)
+        o4, l4, _ = eng.lm_decode_step(big, None, None, 1, -4.0)
+        torch.cuda.synchronize()
+        assert _maxerr(o1.cpu().numpy()[0], o4.cpu().numpy()[2]) < ATOL
+        assert _maxerr(l1.cpu().numpy().reshape(-1)[0], l4.cpu().numpy().reshape(-1)[2]) < 1e-3
+    for s in (whole, parts, clone, one, big):
+        s.close()
