@@ -287,6 +287,10 @@ def main():
             out["kernel_ms_per_step"] = {k: round(v["total_ms"] / nst, 4) for k, v in
                                          sorted(per_kernel.items(), key=lambda kv: -kv[1]["total_ms"])}
             out["kernel_sum_ms_per_step"] = tot / nst
+            # per label: [algorithmic MB per launch, HBM-side MB per launch from the committed PMC passes or null]
+            out["kernel_mb_per_launch"] = {k: [round(v["bytes"] / v["count"] / 1e6, 2),
+                                               (lambda t: None if t is None else round(t / 1e6, 2))(pmc_traffic(k))]
+                                           for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["total_ms"])}
             # the same events grouped by call site (lm.qkv, seanet.convtr2, ...): us per launch, launches per step
             sites = {}
             for r in rows:

@@ -410,12 +410,14 @@ static bool cfg_valid(int cfg, const GemmArgs &a, int pre) {
 }
 
 // XCD-aware mapping (tile_of_block) when the activations outweigh the weights and several column blocks re-read them
+// (PMC: conv k7 with 7.3 MB of weights and 2 MB of activations fetched 112 MB when it was swizzled by rows)
 static int swz_for(int cfg, const GemmArgs &a) {
   static const int swz_env = [] { const char *v = getenv("PTTS_SWZ"); return v ? atoi(v) : -1; }();
   const int *sh = kCfgShape[cfg];
   const int gx = sh[2] == 0 ? cdiv(a.NT, sh[0]) : cdiv(a.NT, sh[0] * sh[3]);
   if (gx <= 1) return 0;
-  return swz_env >= 0 ? swz_env : (a.M > a.NT * 16 && a.MT >= 64);
+  // swizzle when the activations (M x C) outweigh the weights (N x K, K = taps x C)
+  return swz_env >= 0 ? swz_env : ((double)a.M * a.CF > (double)a.NT * 16 * a.KF && a.MT >= 64);
 }
 
 static void launch_by_cfg(hipStream_t st, const GemmArgs &a_in, int pre, int cfg) {
@@ -552,7 +554,14 @@ static void launch_gemm(hipStream_t st, const GemmArgs &a_in, int pre) {
   if (cfg < 0 || !cfg_valid(cfg, a, pre)) cfg = pick_cfg(a);
   if (a.Wq && !cfg_valid(cfg, a, pre)) cfg = 3;
   if (a.Wq) bytes -= 3.0 * N * K;  // one byte per weight
-  ProfScope ps(st, std::string(kCfgName[cfg]) + (pre == PRE_NONE ? "" : pre == PRE_LNFOLD ? "+ln" : pre == PRE_LNMOD ? "+lnmod" : "+addsilu"), bytes, 2.0 * M * N * K);
+  // label = configuration + operand variant + "@<work-items>" (what rocprofv3 reports as Grid_Size), so that the
+  // launches of one label are GEMMs of one grid, i.e. of one (NT, MT) shape class
+  const int *sh = kCfgShape[cfg];
+  const long wgs = sh[2] == 0 ? (long)cdiv(a.NT, sh[0]) * cdiv(a.MT, sh[1])
+                              : (long)cdiv(a.NT, sh[0] * sh[3]) * cdiv(a.MT, sh[1] * sh[4]);
+  const long threads = wgs * (sh[2] == 0 ? 256 : 64 * sh[2] * sh[3] * sh[4]);
+  ProfScope ps(st, std::string(kCfgName[cfg]) + (pre == PRE_NONE ? "" : pre == PRE_LNFOLD ? "+ln" : pre == PRE_LNMOD ? "+lnmod" : "+addsilu") +
+                       (a.Wq ? "+q8" : "") + "@" + std::to_string(threads), bytes, 2.0 * M * N * K);
   launch_by_cfg(st, a, pre, cfg);
 }
 
@@ -636,7 +645,7 @@ static void run_tr_layer(hipStream_t st, const TrLayer &T, const TrCtx &c) {
   SITE(s3.c_str());
   {
     // K and V rows of every attended key once per head + q in + o out
-    ProfScope ps(st, c.Tq == 1 ? "attn_decode" : "attn", c.kv_keys * c.H * 64 * 4 * 2 + 8.0 * c.M * c.D, 4.0 * c.kv_keys * c.H * 64 * std::min(c.Tq, 16));
+    ProfScope ps(st, std::string(c.Tq == 1 ? "attn_decode" : "attn") + "@" + std::to_string((long)BH * c.QB * c.splits * 64), c.kv_keys * c.H * 64 * 4 * 2 + 8.0 * c.M * c.D, 4.0 * c.kv_keys * c.H * 64 * std::min(c.Tq, 16));
     if (c.Tq == 1) attn_decode_kernel<<<dim3(BH, 1, c.splits), 64, 0, st>>>(at);  // one query: vector ALU + wave reductions
     else attn_kernel<<<dim3(BH, c.QB, c.splits), 64, 0, st>>>(at);
   }

@@ -29,7 +29,10 @@ def collect(d, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            a = acc[norm(r["Kernel_Name"])]
+            name = norm(r["Kernel_Name"])
+            if name.startswith(("gemm", "attn")) and not name.startswith("attn_combine"):
+                name += "@" + r["Grid_Size"]  # as bench.py's profiler labels them: one label = one grid = one shape class
+            a = acc[name]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
     return acc
