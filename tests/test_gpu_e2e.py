@@ -242,3 +242,41 @@ def test_continuous_batching_rejects_oversized_request(model):
             cb.submit(state, "   ")
     finally:
         cb.close()
+
+
+def test_continuous_batching_stress_with_noise(model, fx):
+    """40 requests of mixed length through 8 slots at temp 0.7 (device noise, independent per row), submitted from
+    two threads while the scheduler thread runs: every request completes, chunk shapes are right, lengths respect the
+    per-request maximum, samples are finite, and the slots end up parked."""
+    import threading
+
+    from pocket_tts_amd.batching import ContinuousBatcher
+    from pocket_tts_amd.text import estimate_max_gen_len
+
+    state = model.get_state_for_audio_prompt(G / "e2e_voice.safetensors")
+    words = "hello world this is a test of the continuous batching scheduler with many short requests".split()
+    rng = np.random.default_rng(4)
+    texts = [" ".join(rng.choice(words, size=int(rng.integers(1, 9)))) + "." for _ in range(40)]
+    model.temp = 0.7
+    cb = ContinuousBatcher(model, slots=8, capacity=512, noise_seed=11)
+    cb.start()
+    reqs = [None] * len(texts)
+    try:
+        def feed(lo, hi):
+            for i in range(lo, hi):
+                reqs[i] = cb.submit(state, texts[i])
+
+        th = [threading.Thread(target=feed, args=(0, 20)), threading.Thread(target=feed, args=(20, 40))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        outs = [r.result() for r in reqs]
+        assert all(j is None for j in cb.slot) and not cb.waiting
+    finally:
+        model.temp = 0.0
+        cb.close()
+    for t, o in zip(texts, outs):
+        n_tok = len(model.tokenizer.encode(t)) + 8
+        assert o.dim() == 1 and o.shape[0] % 1920 == 0 and torch.isfinite(o).all()
+        assert 0 < o.shape[0] // 1920 <= estimate_max_gen_len(n_tok, model.config.mimi.frame_rate) + 1
