@@ -100,7 +100,7 @@ class Job:
         self.pipe.sync()
 
 
-def first_chunk_latency(eng, args, trials=60):
+def first_chunk_latency(eng, args, trials=200):  # 200 trials: SURVEY 8(d)
     """B=1 streaming path (BASELINE.json configs[1]): time from request (voice state resident) to the
     first 80 ms PCM chunk on the host = state clone + text prefill + 1 LM step + 1 Mimi frame + D2H."""
     B = 1
