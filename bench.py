@@ -201,9 +201,29 @@ def cpu_baseline(args, cfg, W, nsteps):
         x, _, _ = lm.decode_step(st, x, noise, 1, float("inf"))
         dec.decode(ms, x)
     dt = time.perf_counter() - t0
-    return dict(value=B * nsteps * FRAME_S / dt, unit="audio-seconds/sec", cores=os.cpu_count(), kind="port",
-                sample=f"{nsteps} decode steps (LM + Mimi) of batch {B} after voice+text prefill, numpy/BLAS oracle, "
-                       f"{dt:.1f} s wall")
+    out = dict(value=B * nsteps * FRAME_S / dt, unit="audio-seconds/sec", cores=os.cpu_count(), kind="port",
+               sample=f"{nsteps} decode steps (LM + Mimi) of batch {B} after voice+text prefill, numpy/BLAS oracle, "
+                      f"{dt:.1f} s wall")
+    # the reference's own operating point (SURVEY 8d setting (i)): batch 1, one BLAS thread (torch.set_num_threads(1),
+    # tts_model.py:49); LM step and codec frame timed back to back, i.e. without the reference's two-thread overlap
+    try:
+        from threadpoolctl import threadpool_limits
+
+        with threadpool_limits(limits=1):
+            st1 = lm.init_state(1, args.voice_len + args.text_len + 9)
+            lm.prefill(st1, (rng.standard_normal((1, args.voice_len + args.text_len, lm.D)) * 0.1).astype(np.float32))
+            ms1 = dec.init_state(1, 8)
+            x1 = np.full((1, lm.ldim), np.nan, np.float32)
+            t1 = time.perf_counter()
+            for _ in range(8):
+                x1, _, _ = lm.decode_step(st1, x1, None, 1, float("inf"))
+                dec.decode(ms1, x1)
+            d1 = time.perf_counter() - t1
+        out["batch1_one_thread"] = dict(value=8 * FRAME_S / d1, unit="audio-seconds/sec", cores=1,
+                                        sample=f"8 decode steps (LM + Mimi) of batch 1, one BLAS thread, {d1:.2f} s wall")
+    except Exception as e:  # threadpoolctl missing: report only the all-cores figure
+        out["batch1_one_thread"] = dict(error=str(e))
+    return out
 
 
 def main():
