@@ -23,7 +23,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // Ablation switches for tests/hip/bench_gemm.hip only (timing builds; results are wrong when set):
-// 1 = no X loads, 2 = no W loads, 4 = no MFMA.  Always 0 in the library.
+// 1 = no X loads, 2 = no W loads, 4 = no MFMA; gemm_lds_kernel: 8 = no DMA wait, 16 = no stage barrier.
+// Always 0 in the library.
 #ifndef PTTS_ABLATE
 #define PTTS_ABLATE 0
 #endif
@@ -704,10 +705,12 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
     const int cur = s % NS;
     // this wave's DMA of stage s has landed once at most `ahead` later stages' instructions are outstanding
     const int ahead = min(NS - 2, nst - 1 - s);
-    if (ahead >= 2) wait_vmcnt<2 * IPS>();
-    else if (ahead == 1) wait_vmcnt<IPS>();
-    else wait_vmcnt<0>();
-    __syncthreads();  // ... everyone's has, and the buffer of stage s-1 is free again
+    if constexpr (!(PTTS_ABLATE & 8)) {  // ablation 8 (timing only): no DMA wait
+      if (ahead >= 2) wait_vmcnt<2 * IPS>();
+      else if (ahead == 1) wait_vmcnt<IPS>();
+      else wait_vmcnt<0>();
+    }
+    if constexpr (!(PTTS_ABLATE & 16)) __syncthreads();  // ... everyone's has, and the buffer of stage s-1 is free again (ablation 16: no barrier)
     if (s + NS - 1 < nst) issue((s + NS - 1) * KC, (s + NS - 1) % NS);
     // LDS reads are register double-buffered: the fragments of k-step kc+1 are read while the MFMAs of kc run
     // (with one wave per SIMD nothing else would cover the ~128-cycle ds_read latency)
