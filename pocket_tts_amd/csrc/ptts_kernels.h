@@ -1187,9 +1187,12 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
     const int p0 = tile * 16;
     const int slot0 = a.ring ? (p0 % a.ring) : p0;
 #pragma unroll
-    for (int df = 0; df < 4; ++df) kk[df] = *(const f32x4 *)(Kb + (size_t)(slot0 + c) * 64 + 16 * df + 4 * g);
+    // each (sequence, head) streams its keys and values once per launch: non-temporal loads (see attn_decode_kernel)
+    for (int df = 0; df < 4; ++df)
+      kk[df] = __builtin_nontemporal_load((const f32x4 *)(Kb + (size_t)(slot0 + c) * 64 + 16 * df + 4 * g));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) vv[r] = *(const f32x4 *)(Vb + (size_t)(slot0 + 4 * g + r) * 64 + 4 * c);
+    for (int r = 0; r < 4; ++r)
+      vv[r] = __builtin_nontemporal_load((const f32x4 *)(Vb + (size_t)(slot0 + 4 * g + r) * 64 + 4 * c));
   };
   auto process = [&](int tile, const f32x4 *kf4, const f32x4 *vf4) {
     const int p0 = tile * 16;
