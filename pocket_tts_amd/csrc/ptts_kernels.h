@@ -23,7 +23,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // Ablation switches for tests/hip/bench_gemm.hip only (timing builds; results are wrong when set):
-// 1 = no X loads, 2 = no W loads, 4 = no MFMA; gemm_lds_kernel: 8 = no DMA wait, 16 = no stage barrier.
+// 1 = no X loads, 2 = no W loads, 4 = no MFMA; gemm_lds_kernel: 8 = no DMA wait, 16 = no stage barrier, 32 = no DMA after the prologue.
 // Always 0 in the library.
 #ifndef PTTS_ABLATE
 #define PTTS_ABLATE 0
@@ -366,6 +366,28 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
     cf = k0 - tap * a.CF;
   }
   const int halo = a.halo;
+  // Incremental operand addressing (as in gemm_lds_kernel): fragment (row tile j, tap, cf) sits at
+  // xrow[j] + cf * 1 KiB; the per-lane 64-bit row arithmetic is redone only when the tap changes.
+  const float *xrow[TM];
+  bool xz[TM];
+  auto row_base = [&](int j, int tp) {
+    if (a.ntaps == 1) {
+      xrow[j] = Xc + (((size_t)mtc[j] * a.XF) * 64 + lane) * 4;
+      xz[j] = false;
+      return;
+    }
+    const int ts = tin[j] * a.xstride + tp - halo;
+    const float *src = Xc;
+    long rr = (long)bT[j] * a.xstride + ts;
+    if (ts < 0) {
+      if (a.halo_mode == 0) { src = Xp; rr += (long)a.T * a.xstride; }
+      else if (a.halo_mode == 2) rr = (long)bT[j] * a.xstride;
+    }
+    xrow[j] = src + (((size_t)(rr >> 4) * a.XF) * 64 + (lane & 48) + (rr & 15)) * 4;
+    xz[j] = ts < 0 && a.halo_mode == 1;
+  };
+#pragma unroll
+  for (int j = 0; j < TM; ++j) row_base(j, tap);
   // Software pipeline over chunks of U k-fragments: the 1 KiB operand loads of chunk c+1 are issued before the
   // MFMAs of chunk c, into a second register set, so the matrix pipe works while the next operands fly.
   // decode (K-split) tiles: as many fragments per round as the register file allows, so that a wave needs
@@ -397,23 +419,15 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
         // s_waitcnt insertion merge the paths conservatively and serialise the prefetch (see attn_kernel)
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-          const float *ptr;
-          if (a.ntaps == 1) {
-            ptr = Xc + (((size_t)mtc[j] * a.XF + kf + u) * 64 + lane) * 4;
-          } else {
-            const int ts = tin[j] * a.xstride + tap - halo;
-            const float *src = Xc;
-            long rr = (long)bT[j] * a.xstride + ts;
-            if (ts < 0) {
-              if (a.halo_mode == 0) { src = Xp; rr += (long)a.T * a.xstride; }
-              else if (a.halo_mode == 2) rr = (long)bT[j] * a.xstride;
-            }
-            ptr = src + (((size_t)(rr >> 4) * a.XF + cf) * 64 + (lane & 48) + (rr & 15)) * 4;
-            if (ts < 0 && a.halo_mode == 1) ptr = a.zeros;
-          }
+          const float *ptr = xz[j] ? a.zeros : xrow[j] + (size_t)cf * 256;
           x[u][j] = *(const f32x4 *)ptr;
         }
-        if (++cf == a.CF) { cf = 0; ++tap; }
+        if (++cf == a.CF) {  // next tap: the rows move by one (a Linear has CF == KF: never taken before the end)
+          cf = 0;
+          ++tap;
+#pragma unroll
+          for (int j = 0; j < TM; ++j) row_base(j, tap);
+        }
       }
     }
   };
@@ -651,41 +665,61 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
     l_t[q] = t;
     l_bT[q] = row - t;
   }
+  // Incremental addressing.  The DMA source of fragment (row tile, tap, cf) is  row_base(tap) + cf * 1 KiB: the
+  // per-lane 64-bit row arithmetic (tile / halo / previous-frame selection) is redone only when the tap changes,
+  // i.e. once per CF k-fragments, and the tap / cf position is a running scalar state instead of a division per
+  // fragment.  Measured with the DMA removed (-DPTTS_ABLATE=32): the old per-fragment arithmetic + the fetch cost
+  // 20 % (Linear) to 60 % (conv k7) of these kernels.  issue() must be called once per stage, in k order.
+  const float *xp[XPW];
+  bool xz[XPW];
+  int s_cf = 0, s_tap = 0;
+  auto row_base = [&](int q, int tap) {
+    if (a.ntaps == 1) {
+      xp[q] = Xc + (((size_t)l_mt[q] * a.XF) * 64 + lane) * 4;
+      xz[q] = false;
+      return;
+    }
+    const int ts = l_t[q] * a.xstride + tap - halo;
+    const float *base = Xc;
+    long rr = (long)l_bT[q] * a.xstride + ts;
+    if (ts < 0) {
+      if (a.halo_mode == 0) { base = Xp; rr += (long)a.T * a.xstride; }
+      else if (a.halo_mode == 2) rr = (long)l_bT[q] * a.xstride;
+    }
+    xp[q] = base + (((size_t)(rr >> 4) * a.XF) * 64 + (lane & 48) + (rr & 15)) * 4;
+    xz[q] = ts < 0 && a.halo_mode == 1;  // whole-signal zero padding: every cf reads the zero line
+  };
+#pragma unroll
+  for (int q = 0; q < XPW; ++q) row_base(q, 0);
+  // W fragments f = wave + 4 i of a stage (index NX + f = NX + kc * BNT + n): base pointers at k-fragment 0
+  constexpr int WPW = BNT * KC / 4;
+  const float *wp[WPW];
+  int wslot[WPW];
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) {
+    const int f = wave + 4 * i, kc = f / BNT, n = f - kc * BNT;
+    const int nt = nt0 + n < a.NT ? nt0 + n : a.NT - 1;
+    wp[i] = a.W + ((size_t)nt * a.KF + kc) * 256 + lane * 4;
+    wslot[i] = NX + f;
+  }
   auto issue = [&](int kf0, int buf) {
     // X fragments: index kc * BMT + m, m = wave + 4q
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
-      const int kf = kf0 + kc;
-      int tap = 0, cf = kf;
-      if (a.ntaps > 1) { tap = kf / a.CF; cf = kf - tap * a.CF; }
 #pragma unroll
       for (int q = 0; q < XPW; ++q) {
-        const float *src;
-        if (a.ntaps == 1) {
-          src = Xc + (((size_t)l_mt[q] * a.XF + kf) * 64 + lane) * 4;
-        } else {
-          const int ts = l_t[q] * a.xstride + tap - halo;
-          const float *base = Xc;
-          long rr = (long)l_bT[q] * a.xstride + ts;
-          if (ts < 0) {
-            if (a.halo_mode == 0) { base = Xp; rr += (long)a.T * a.xstride; }
-            else if (a.halo_mode == 2) rr = (long)l_bT[q] * a.xstride;
-          }
-          src = base + (((size_t)(rr >> 4) * a.XF + cf) * 64 + (lane & 48) + (rr & 15)) * 4;
-          if (ts < 0 && a.halo_mode == 1) src = a.zeros;
-        }
+        const float *src = xz[q] ? a.zeros : xp[q] + (size_t)s_cf * 256;
         GLDS16(src, &lds[buf][kc * BMT + wave + 4 * q][0]);
       }
-    }
-    // W fragments: index NX + kc * BNT + n, distributed round-robin over the 4 waves
+      if (++s_cf == a.CF) {  // next tap: one row further (a.CF == a.KF for a Linear: never taken)
+        s_cf = 0;
+        ++s_tap;
 #pragma unroll
-    for (int f = 0; f < BNT * KC; ++f) {
-      if ((f & 3) != wave) continue;
-      const int kc = f / BNT, n = f - kc * BNT;
-      int nt = nt0 + n;
-      nt = nt < a.NT ? nt : a.NT - 1;
-      GLDS16(a.W + ((size_t)nt * a.KF + kf0 + kc) * 256 + lane * 4, &lds[buf][NX + f][0]);
+        for (int q = 0; q < XPW; ++q) row_base(q, s_tap);
+      }
     }
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) GLDS16(wp[i] + (size_t)kf0 * 256, &lds[buf][wslot[i]][0]);
   };
 
   f32x4 acc[WNT][WMT];
@@ -711,7 +745,8 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
       else wait_vmcnt<0>();
     }
     if constexpr (!(PTTS_ABLATE & 16)) __syncthreads();  // ... everyone's has, and the buffer of stage s-1 is free again (ablation 16: no barrier)
-    if (s + NS - 1 < nst) issue((s + NS - 1) * KC, (s + NS - 1) % NS);
+    if constexpr (!(PTTS_ABLATE & 32))  // ablation 32 (timing only): no operand DMA after the prologue
+      if (s + NS - 1 < nst) issue((s + NS - 1) * KC, (s + NS - 1) % NS);
     // LDS reads are register double-buffered: the fragments of k-step kc+1 are read while the MFMAs of kc run
     // (with one wave per SIMD nothing else would cover the ~128-cycle ds_read latency)
     f32x4 xa[WMT], wa[WNT], xb[WMT], wb[WNT];
