@@ -329,7 +329,7 @@ def main():
                                         "frac": bytes_step / 8e12 / (wall / args.steps)}
         if not args.no_latency and world == 1:
             out["latency_b1"] = first_chunk_latency(eng, args)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args, cfg, W, args.cpu_steps)
         print(json.dumps(out), flush=True)
     if dist is not None:
