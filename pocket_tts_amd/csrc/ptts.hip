@@ -120,6 +120,7 @@ struct ptts_lm_state {
   Scratch dec, pre;
   // flow head scratch (FM) + io
   float *xlat, *c, *ce, *mod, *latfm, *fx, *fh, *f1;
+  float *fstat = nullptr;  // per-tile row statistics of fx (GemmArgs::stat_out / stat_in)
   float *lat, *lat_prev;  // plain [B][ldim]
   float *eos_logit;
   uint8_t *is_eos;
@@ -942,6 +943,7 @@ static int build_lm_state(ptts_engine *e, ptts_lm_state *s) {
   CHK(dallocT(nullptr, &s->fx, rt * (FD / 16)));
   CHK(dallocT(nullptr, &s->fh, rt * (FD / 16)));
   CHK(dallocT(nullptr, &s->f1, rt * (FD / 16)));
+  CHK(dallocT(nullptr, &s->fstat, (size_t)s->MT * (FD / 16) * 32));
   CHK(dallocT(nullptr, &s->lat, (size_t)B * c.ldim));
   CHK(dallocT(nullptr, &s->lat_prev, (size_t)B * c.ldim));
   CHK(dallocT(nullptr, &s->eos_logit, B));
@@ -963,7 +965,7 @@ extern "C" void ptts_lm_state_destroy(ptts_lm_state *s) {
   free_scratch(&s->dec);
   if (s->pre.x) free_scratch(&s->pre);
   hipFree(s->xlat); hipFree(s->latfm); hipFree(s->c); hipFree(s->ce); hipFree(s->mod); hipFree(s->fx);
-  hipFree(s->fh); hipFree(s->f1); hipFree(s->lat); hipFree(s->lat_prev); hipFree(s->eos_logit); hipFree(s->is_eos); hipFree(s->rng_ctr); hipFree(s->active);
+  hipFree(s->fh); hipFree(s->f1); hipFree(s->lat); hipFree(s->lat_prev); hipFree(s->eos_logit); hipFree(s->is_eos); hipFree(s->rng_ctr); hipFree(s->active); hipFree(s->fstat);
   delete s;
 }
 
@@ -1221,6 +1223,7 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
     SITE("flow.input_proj");
     a = mk_gemm(e->input_proj, s->latfm, LF, MT, B);
     a.Y = s->fx; a.YF = FDF;
+    a.stat_out = s->fstat;  // row statistics of x for the first block's LayerNorm
     launch_gemm(st, a, PRE_NONE);
     for (int r = 0; r < c.flow_depth; ++r) {
       const float *shift = s->mod + (size_t)(r * 3 * FDF) * 256;
@@ -1231,10 +1234,12 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
       a.act = ACT_SILU; a.Y = s->f1; a.YF = FDF;
       a.lnm_w = e->res[r].ln_w; a.lnm_b = e->res[r].ln_b; a.mod_shift = shift; a.mod_scale = scale; a.modF = AF;
       a.ln_eps = 1e-6f;  // flow-MLP LayerNorm eps (mlp.py:95)
+      a.stat_in = s->fstat; a.stat_nt = FDF;
       launch_gemm(st, a, PRE_LNMOD);
       SITE("flow.res.l2");
       a = mk_gemm(e->res[r].l2, s->f1, FDF, MT, B);
       a.epi = EPI_GATE; a.R = s->fx; a.RF = FDF; a.G = gate; a.GF = AF; a.Y = s->fx; a.YF = FDF;
+      a.stat_out = s->fstat;  // ... of the updated x for the next block / the final layer
       launch_gemm(st, a, PRE_NONE);
     }
     const float *shift = s->mod + (size_t)(c.flow_depth * 3 * FDF) * 256;
@@ -1242,6 +1247,7 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
     SITE("flow.final");  // norm_final (no affine) + modulate on load
     a = mk_gemm(e->fin, s->fx, FDF, MT, B);
     a.lnm_w = nullptr; a.lnm_b = nullptr; a.mod_shift = shift; a.mod_scale = scale; a.modF = AF; a.ln_eps = 1e-6f;
+    a.stat_in = s->fstat; a.stat_nt = FDF;
     a.epi = EPI_LATENT; a.lat = s->lat; a.ldim = c.ldim; a.inv_steps = 1.0f / (float)lsd_steps; a.Y = s->latfm; a.YF = LF;
     if (i == lsd_steps - 1) { a.lat_out1 = s->lat_prev; a.lat_out2 = d_latent_out; }  // next step's input + caller's copy
     launch_gemm(st, a, PRE_LNMOD);

@@ -23,7 +23,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // Ablation switches for tests/hip/bench_gemm.hip only (timing builds; results are wrong when set):
-// 1 = no X loads, 2 = no W loads, 4 = no MFMA; gemm_lds_kernel: 8 = no DMA wait, 16 = no stage barrier, 32 = no DMA after the prologue.
+// 1 = no X loads, 2 = no W loads, 4 = no MFMA; gemm_lds_kernel: 8 = no DMA wait, 16 = no stage barrier, 32 = no DMA after the prologue;
+// gemm_kernel: 64 = no PRE_LNMOD statistics pass.
 // Always 0 in the library.
 #ifndef PTTS_ABLATE
 #define PTTS_ABLATE 0
@@ -61,6 +62,12 @@ struct GemmArgs {
   const uint8_t *Wq;
   const float *wscale;
   int swz;  // XCD-aware workgroup -> tile mapping (tile_of_block)
+  // Row statistics hand-over (flow MLP): a producer (EPI_STORE / EPI_GATE) also writes, per output tile, each row's
+  // (sum, sum of squares) over the tile's 16 columns to stat_out[((mt * NT + nt) * 16 + row) * 2]; the PRE_LNMOD
+  // consumer then adds stat_nt partials per row instead of re-reading the whole row (fixed order, deterministic).
+  float *stat_out;
+  const float *stat_in;
+  int stat_nt;
   const float *ln_g;  // Q8 + PRE_LNFOLD: the LayerNorm gain stays out of the quantised matrix and scales x on load
   int NT, KF, CF, ntaps;
   // input FM view; double-buffered by frame parity when Xdstride != 0
@@ -146,6 +153,19 @@ __device__ __forceinline__ f32x4 pre4(f32x4 x, const float *prevec, int kf, int 
   return x;
 }
 
+// (sum, sum of squares) of each row over the 16 columns of one output tile: lanes l, l^16, l^32, l^48 hold the row
+__device__ __forceinline__ void tile_row_stats(const GemmArgs &a, f32x4 v, int nt, int mt, int lane) {
+  float s1 = (v.x + v.y) + (v.z + v.w);
+  float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+  s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+  if (lane < 16) {
+    float *p = a.stat_out + (((size_t)mt * a.NT + nt) * 16 + lane) * 2;
+    p[0] = s1;
+    p[1] = s2;
+  }
+}
+
 // Epilogue operands a wave can fetch at kernel START for the tiles it will finish (K-split path): bias, residual
 // and gate tiles, LN-fold vectors, int8 scales.  Loaded after the reduction they would add one dependent L2 round
 // trip (~0.6 us) to every decode GEMM.
@@ -168,6 +188,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 acc, int 
       acc = act4(acc, a.act);
       float *y = a.Y + par * a.Ydstride;
       *(f32x4 *)(y + (((size_t)mt * a.YF + nt) * 64 + lane) * 4) = acc;
+      if (a.stat_out) tile_row_stats(a, acc, nt, mt, lane);
     } break;
     case EPI_RES: {
       const float *r = a.R + par * a.Rdstride;
@@ -179,7 +200,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 acc, int 
     case EPI_GATE: {
       f32x4 rv = pf ? pf->r : *(const f32x4 *)(a.R + (((size_t)mt * a.RF + nt) * 64 + lane) * 4);
       f32x4 gv = pf ? pf->g : *(const f32x4 *)(a.G + (((size_t)mt * a.GF + nt) * 64 + lane) * 4);
-      *(f32x4 *)(a.Y + (((size_t)mt * a.YF + nt) * 64 + lane) * 4) = rv + gv * acc;
+      const f32x4 out = rv + gv * acc;
+      *(f32x4 *)(a.Y + (((size_t)mt * a.YF + nt) * 64 + lane) * 4) = out;
+      if (a.stat_out) tile_row_stats(a, out, nt, mt, lane);
     } break;
     case EPI_QKV: {
       // packed in_proj rows: [q | k | v] x [H][64]  (reference transformer.py:138-143)
@@ -305,11 +328,28 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
     bT[j] = row - t;
   }
   float lmu[TM], lrs[TM];  // PRE_LNMOD row statistics
-  if constexpr (PRE == PRE_LNMOD) {
-    // pre-pass over the (short, L2-resident) rows: 8 independent loads in flight per batch
+  if constexpr (PRE == PRE_LNMOD && (PTTS_ABLATE & 64)) {  // ablation 64 (timing only): no statistics pass
+#pragma unroll
+    for (int j = 0; j < TM; ++j) { lmu[j] = 0.f; lrs[j] = 1.f; }
+  } else if constexpr (PRE == PRE_LNMOD) {
+    // pre-pass over the (short, L2-resident) rows: 8 independent loads in flight per batch; or, when the producer
+    // handed over per-tile partials (stat_in), stat_nt / 4 eight-byte loads per lane
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       float s1 = 0.f, s2 = 0.f;
+      if (a.stat_in) {
+        const float *sp = a.stat_in + (((size_t)mtc[j] * a.stat_nt) * 16 + (lane & 15)) * 2;
+        for (int t = lane >> 4; t < a.stat_nt; t += 4) {  // lane group g adds tiles g, g+4, ..
+          s1 += sp[(size_t)t * 32];
+          s2 += sp[(size_t)t * 32 + 1];
+        }
+        s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+        const float invK = 1.0f / (float)(a.KF * 16);
+        lmu[j] = s1 * invK;
+        lrs[j] = 1.0f / sqrtf(fmaxf(s2 * invK - lmu[j] * lmu[j], 0.f) + a.ln_eps);
+        continue;
+      }
       const float *xr = Xc + ((size_t)mtc[j] * a.XF * 64 + lane) * 4;
       int kf = 0;
       for (; kf + 8 <= a.KF; kf += 8) {
