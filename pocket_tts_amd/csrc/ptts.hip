@@ -599,9 +599,14 @@ static GemmArgs mk_gemm(const Lin &L, const float *X, int XF, int MT, int M) {
   return a;
 }
 
-// waves per (sequence, head, key split) in the decode attention: 2 and 4 (LDS merge) were measured no faster than 1
-// at batch 1 and 64 once the K/V loads are non-temporal; PTTS_ATTN_NW overrides for experiments
-static constexpr int kDecodeAttnWaves = 1;
+// waves per (sequence, head) in the decode attention: enough to reach the wave target, at most 8 (one workgroup)
+static int decode_attn_waves(int BH) {
+  static const int forced = [] { const char *v = getenv("PTTS_ATTN_NW"); return v ? atoi(v) : 0; }();
+  if (forced) return forced;
+  int nw = 1;
+  while (nw < 8 && BH * nw * 2 <= 1024) nw *= 2;
+  return nw;
+}
 static int attn_wave_target() {
   static int t = [] { const char *v = getenv("PTTS_ATTN_WAVES"); return v ? atoi(v) : 1024; }();
   return t;
@@ -649,12 +654,14 @@ static void run_tr_layer(hipStream_t st, const TrLayer &T, const TrCtx &c) {
   SITE(s3.c_str());
   {
     // K and V rows of every attended key once per head + q in + o out
-    ProfScope ps(st, std::string(c.Tq == 1 ? "attn_decode" : "attn") + "@" + std::to_string((long)BH * c.QB * c.splits * 64 * (c.Tq == 1 ? kDecodeAttnWaves : 1)), c.kv_keys * c.H * 64 * 4 * 2 + 8.0 * c.M * c.D, 4.0 * c.kv_keys * c.H * 64 * std::min(c.Tq, 16));
-    if (c.Tq == 1) {  // one query: vector ALU + wave reductions, kDecodeAttnWaves waves per (sequence, head, split)
-      static const int nw = [] { const char *v = getenv("PTTS_ATTN_NW"); return v ? atoi(v) : kDecodeAttnWaves; }();
-      if (nw >= 4) attn_decode_kernel<4><<<dim3(BH, 1, c.splits), 256, 0, st>>>(at);
+    ProfScope ps(st, std::string(c.Tq == 1 ? "attn_decode" : "attn") + "@" + std::to_string((long)BH * c.QB * c.splits * 64 * (c.Tq == 1 ? decode_attn_waves(BH) : 1)), c.kv_keys * c.H * 64 * 4 * 2 + 8.0 * c.M * c.D, 4.0 * c.kv_keys * c.H * 64 * std::min(c.Tq, 16));
+    if (c.Tq == 1) {
+      // one query: vector ALU + wave reductions.  The keys of a (sequence, head) are split over the nw waves of ONE
+      // workgroup and merged in LDS, so small batches reach ~1024 waves without partial buffers or a combine launch
+      const int nw = decode_attn_waves(BH);
+      if (nw >= 8) attn_decode_kernel<8><<<dim3(BH, 1, c.splits), 512, 0, st>>>(at);
+      else if (nw == 4) attn_decode_kernel<4><<<dim3(BH, 1, c.splits), 256, 0, st>>>(at);
       else if (nw == 2) attn_decode_kernel<2><<<dim3(BH, 1, c.splits), 128, 0, st>>>(at);
-      else if (getenv("PTTS_ATTN_PLAIN")) attn_decode_kernel<1, false><<<dim3(BH, 1, c.splits), 64, 0, st>>>(at);
       else attn_decode_kernel<1><<<dim3(BH, 1, c.splits), 64, 0, st>>>(at);
     }
     else attn_kernel<<<dim3(BH, c.QB, c.splits), 64, 0, st>>>(at);
@@ -1147,8 +1154,8 @@ static void lm_layers(hipStream_t st, ptts_engine *e, ptts_lm_state *s, Scratch 
     TrCtx t;
     t.D = c.d_model; t.H = c.num_heads; t.FF = c.ff_dim; t.MT = sc.MT; t.M = M; t.Tq = Tq; t.QB = sc.QB;
     t.cap = s->cap; t.ring = 0; t.ctx = 0;
-    // decode steps run kDecodeAttnWaves waves per workgroup, so fewer key splits reach the wave target
-    t.splits = std::min(sc.splits_cap, attn_splits(s->B * c.num_heads * sc.QB * (Tq == 1 ? kDecodeAttnWaves : 1), cdiv(s->cap, 16)));
+    // decode steps split the keys over the waves of a workgroup (decode_attn_waves): no key splits, no combine launch
+    t.splits = Tq == 1 ? 1 : std::min(sc.splits_cap, attn_splits(s->B * c.num_heads * sc.QB, cdiv(s->cap, 16)));
     t.x_in = sc.x; t.x = sc.x; t.x_out = sc.x; t.out_ds = 0; t.par = nullptr;
     t.h = sc.h; t.ao = sc.ao; t.ff = sc.ff; t.q = sc.q; t.part = sc.part;
     t.Kc = s->K(l); t.Vc = s->V(l); t.offset = s->offset; t.rope = sc.rope;
