@@ -87,3 +87,26 @@ def test_eos_bookkeeping_matches_reference_loop():
             eos, n_emit = f(step, n, fae, eos, flags[step] if step < len(flags) else False)
             step += 1
         assert n_emit == reference(flags, n, fae), (flags, n, fae)
+
+
+def test_pmc_tool_labels_match_the_profiler_labels():
+    """tools/pmc_traffic.py turns rocprofv3's demangled kernel names into the labels bench.py's profiler uses
+    (configuration + operand variant, '@<work-items>' appended by the caller), so that `roofline.traffic` finds them."""
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("pmc_traffic", Path(__file__).parent.parent / "tools" / "pmc_traffic.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n = mod.norm
+    assert n("void gemm_kernel<1, 1, 8, 1, 1, 3, false>(GemmArgs)") == "gemm<1,1,8,1,1>+ln"
+    assert n("void gemm_kernel<2, 2, 4, 1, 1, 0, false>(GemmArgs)") == "gemm<2,2,4,1,1>"
+    assert n("void gemm_kernel<1, 1, 4, 1, 1, 4, false>(GemmArgs)") == "gemm<1,1,4,1,1>+lnmod"
+    assert n("void gemm_kernel<2, 2, 4, 1, 1, 2, false>(GemmArgs)") == "gemm<2,2,4,1,1>+addsilu"
+    assert n("void gemm_kernel<1, 2, 4, 1, 1, 3, true>(GemmArgs)") == "gemm<1,2,4,1,1>+ln+q8"
+    assert n("void gemm_lds_kernel<4, 4, 2, 3, 2>(GemmArgs)") == "gemm_lds<4,4,2>+ln"
+    assert n("void gemm_lds_kernel<4, 2, 2, 0, 2>(GemmArgs)") == "gemm_lds<4,2,2>"
+    assert n("void attn_decode_kernel<1, true>(AttnArgs)") == "attn_decode"
+    assert n("attn_kernel(AttnArgs)") == "attn"
+    assert n("attn_combine_kernel(AttnArgs)") == "attn_combine"
+    assert n("step_tail_kernel(int*, int, int, int*, int const*)") == "step_tail"
