@@ -24,7 +24,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // Ablation switches for tests/hip/bench_gemm.hip only (timing builds; results are wrong when set):
 // 1 = no X loads, 2 = no W loads, 4 = no MFMA; gemm_lds_kernel: 8 = no DMA wait, 16 = no stage barrier, 32 = no DMA after the prologue;
-// gemm_kernel: 64 = no PRE_LNMOD statistics pass.
+// gemm_kernel: 64 = no PRE_LNMOD statistics pass; 128 = GEMM and attention kernels return at once.
 // Always 0 in the library.
 #ifndef PTTS_ABLATE
 #define PTTS_ABLATE 0
@@ -281,6 +281,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 acc, int 
 // TN x TM 16x16 tiles per wave; WK waves split K (LDS-reduced), WN x WM waves tile N x M.
 template <int TN, int TM, int WK, int WN, int WM, int PRE, bool Q8 = false>
 __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
+  if constexpr (PTTS_ABLATE & 128) return;  // ablation 128 (timing only): empty kernels = launch + boundary cost
   constexpr int NW = WK * WN * WM;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -674,6 +675,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 template <int BMT, int BNT, int KC, int PRE, int NS = 2>
 __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
+  if constexpr (PTTS_ABLATE & 128) return;
   static_assert(BMT % 4 == 0 && BNT % 2 == 0 && (BNT * KC) % 4 == 0, "tile shape");
   static_assert(NS >= 2 && NS <= 4, "stage count");
   constexpr int WMT = BMT / 2, WNT = BNT / 2;  // tiles per wave
@@ -1232,6 +1234,7 @@ __device__ __forceinline__ void attn_store_out(const AttnArgs &a, int b, int h, 
 }
 
 __global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
+  if constexpr (PTTS_ABLATE & 128) return;
   const int bh = blockIdx.x, qb = blockIdx.y, sp = blockIdx.z;
   const int b = bh / a.H, h = bh - b * a.H;
   const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
@@ -1379,6 +1382,7 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
 // partial results meet in LDS, so a CU has NW times the bytes in flight without extra partial buffers or launches.
 template <int NW, bool NT = true>
 __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(AttnArgs a) {
+  if constexpr (PTTS_ABLATE & 128) return;
   const int bh = blockIdx.x, sp = blockIdx.z;
   const int b = bh / a.H, h = bh - b * a.H;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
