@@ -526,6 +526,11 @@ static void launch_gemm(hipStream_t st, const GemmArgs &a_in, int pre) {
   const double K = (double)a.KF * 16, N = (double)a.NT * 16, M = (double)a.M;
   double bytes = 4.0 * (N * K + M * (double)a.CF * 16 + M * N);
   if (a.epi == EPI_RES || a.epi == EPI_GATE) bytes += 4.0 * M * N;
+  if (a.epi == EPI_PCM && a.NT == 1 && pre == PRE_NONE && !a.Wq && a.CF == 4 && a.ntaps <= 4) {  // one output channel: vector-ALU kernel
+    ProfScope ps(st, "pcm_conv", 4.0 * (M * (double)a.CF * 16 + M), 2.0 * M * K);
+    pcm_conv_kernel<<<cdiv(a.MT, 4), 256, 0, st>>>(a);
+    return;
+  }
   int cfg = -1;
   if (g_tuner) {
     const TuneKey key = tune_key(a, pre);

@@ -657,6 +657,61 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Single-output-channel causal conv (SEANet's last conv: n_filters -> 1 sample, reference seanet.py:168-172) on
+// the vector ALU.  As a GEMM it would use one of 16 MFMA rows; here a wave owns 16 output rows, lane (row, g)
+// dots its quarter of the channels for every tap and the four quarters meet by two xor-shuffles.  Memory bound:
+// every input row is read once from HBM, the other taps re-read its lines through L1 (plain loads on purpose).  Same GemmArgs (taps, halo rule, frame-parity double buffer, packed weights with NT = 1).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pcm_conv_kernel(GemmArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mt = blockIdx.x * 4 + wave;
+  if (mt >= a.MT) return;
+  const int par = a.par ? (*a.par & 1) : 0;
+  const float *Xc = a.X + par * a.Xdstride;
+  const float *Xp = a.X + (par ^ 1) * a.Xdstride;
+  const int row = 16 * mt + (lane & 15);
+  const int t = a.ntaps > 1 ? row % a.T : 0;
+  const int bT = row - t;
+  // CF == 4 channel fragments, at most 4 taps (host-checked): all 32 loads of a lane are issued before the first
+  // FMA, branch-free (a missing tap reads the zero line), so a wave pays one memory round trip
+  f32x4 x[4][4], w[4][4];
+#pragma unroll
+  for (int tap = 0; tap < 4; ++tap) {
+    const bool have = tap < a.ntaps;
+    const int tp = have ? tap : a.ntaps - 1;
+    const int ts = t * a.xstride + tp - a.halo;
+    const float *src = Xc;
+    long rr = (long)bT * a.xstride + ts;
+    if (ts < 0) {
+      if (a.halo_mode == 0) { src = Xp; rr += (long)a.T * a.xstride; }
+      else if (a.halo_mode == 2) rr = (long)bT * a.xstride;
+    }
+    const float *xr = src + (((size_t)(rr >> 4) * a.XF) * 64 + (lane & 48) + (rr & 15)) * 4;
+    const bool zero = !have || (ts < 0 && a.halo_mode == 1);
+    // weights of output channel 0: packed element (n = 0, k) sits in lane 16 * ((k % 16) / 4) of fragment k / 16
+    const float *wr = a.W + ((size_t)tp * 4 * 64 + (lane & 48)) * 4;
+#pragma unroll
+    for (int cf = 0; cf < 4; ++cf) {
+      x[tap][cf] = *(const f32x4 *)(zero ? a.zeros : xr + (size_t)cf * 256);  // plain: the taps re-read lines through L1
+      w[tap][cf] = *(const f32x4 *)(wr + (size_t)cf * 256);
+    }
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 4; ++tap)
+#pragma unroll
+    for (int cf = 0; cf < 4; ++cf)
+      acc += (x[tap][cf].x * w[tap][cf].x + x[tap][cf].y * w[tap][cf].y) + (x[tap][cf].z * w[tap][cf].z + x[tap][cf].w * w[tap][cf].w);
+  acc += __shfl_xor(acc, 16);
+  acc += __shfl_xor(acc, 32);
+  if (lane < 16 && row < a.M) {
+    if (a.bias) acc += a.bias[0];
+    a.pcm[row] = acc;
+    if (a.pcm_i16) a.pcm_i16[row] = (int16_t)(fminf(fmaxf(acc, -1.0f), 1.0f) * 32767.0f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LDS-staged variant for the large-M GEMMs of the codec (rows = sequences x time).  A workgroup of 4 waves
 // (2 x 2) owns BMT x BNT 16x16 tiles.  Per stage of KC k-fragments every operand fragment is copied ONCE per
 // workgroup by `global_load_lds_dwordx4` (1 KiB, wave-linear = exactly the FM / packed fragment image, no VGPRs),
