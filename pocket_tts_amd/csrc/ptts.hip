@@ -92,7 +92,7 @@ struct ptts_engine {
   float *te_scratch = nullptr;
   // Mimi
   float *emb_std, *emb_mean, *up_w, *freq_mimi;
-  Lin quant;
+  float *quant_w = nullptr;  // quantizer.output_proj weight [C][ldim], plain (mimi_prologue_kernel)
   std::vector<TrLayer> mm;
   Lin conv0, convtr[3], res_a[3], res_b[3], conv_last;
   int ring = 0;
@@ -788,7 +788,7 @@ static int build_engine(ptts_engine *e, const ptts_tensor *tensors, int32_t n) {
   CHK(copy_vec(e, p + "emb_std", c.ldim, &e->emb_std));
   CHK(copy_vec(e, p + "emb_mean", c.ldim, &e->emb_mean));
   const int C = c.m_dim;
-  CHK(pack_lin(e, &e->quant, {{"mimi.quantizer.output_proj.weight", "", C}}, c.ldim, 1));
+  CHK(copy_vec(e, "mimi.quantizer.output_proj.weight", (int64_t)C * c.ldim, &e->quant_w));
   CHK(copy_vec(e, "mimi.upsample.convtr.convtr.weight", (int64_t)C * 2 * c.upsample_stride, &e->up_w));
   CHK(make_freq(e, &e->freq_mimi, c.m_max_period));
   e->mm.resize(c.m_layers);
@@ -841,7 +841,7 @@ static int build_engine(ptts_engine *e, const ptts_tensor *tensors, int32_t n) {
     CHK(pack_lin(e, &e->speaker_proj, {{"flow_lm.speaker_proj_weight", "", D}}, c.ldim, 1));
     e->has_encoder = true;
   }
-  e->mimi_bytes = e->quant.bytes() + e->conv0.bytes() + e->conv_last.bytes();
+  e->mimi_bytes = (int64_t)C * c.ldim * 4 + e->conv0.bytes() + e->conv_last.bytes();
   for (auto &L : e->mm) e->mimi_bytes += L.qkv.bytes() + L.out.bytes() + L.ff1.bytes() + L.ff2.bytes();
   for (int i = 0; i < 3; ++i) e->mimi_bytes += e->convtr[i].bytes() + e->res_a[i].bytes() + e->res_b[i].bytes();
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -1416,23 +1416,15 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
   const ptts_config &c = e->cfg;
   bind_engine(e);
   const int B = s->B, C = c.m_dim, CF = C / 16, LF = c.ldim / 16, st16 = c.upsample_stride;
-  SITE("mimi.prep");
+  SITE("mimi.prologue");  // de-normalise + quantizer 1x1 conv + depthwise x16 upsample + RoPE table: one launch
   {
-    ProfScope ps(st, "prep_mimi", 8.0 * B * c.ldim, 0);
-    const int nb_prep = cdiv(s->MTb * LF * 64, 256);
-    prep_mimi_kernel<<<nb_prep + cdiv(B * st16 * 32, 256), 256, 0, st>>>(d_latent, e->emb_std, e->emb_mean, s->zl, B, c.ldim, s->MTb, nb_prep,
-                                                                          RopeArgs{s->offset, e->freq_mimi, s->rope, B * st16, st16});
+    ProfScope ps(st, "mimi_prologue", 4.0 * (B * c.ldim + (double)C * c.ldim + B * C * (2.0 + st16)), 2.0 * B * C * (c.ldim + 2.0 * st16));
+    const int nb_main = cdiv((long)B * (C / 4) * st16, 256);
+    mimi_prologue_kernel<<<nb_main + cdiv(B * st16 * 32, 256), 256, 0, st>>>(
+        d_latent, e->emb_std, e->emb_mean, e->quant_w, e->up_w, s->zq, s->zq_stride, s->frame, s->u0, B, c.ldim, C, st16,
+        nb_main, RopeArgs{s->offset, e->freq_mimi, s->rope, B * st16, st16});
   }
-  SITE("mimi.quant");
-  GemmArgs a = mk_gemm(e->quant, s->zl, LF, s->MTb, B);
-  a.Y = s->zq; a.Ydstride = s->zq_stride; a.YF = CF; a.par = s->frame;
-  launch_gemm(st, a, PRE_NONE);
-  long tot = (long)B * st16 * (C / 4);
-  SITE("mimi.upsample");
-  {
-    ProfScope ps(st, "upsample", 4.0 * B * C * (2 + st16), 0);
-    upsample_kernel<<<cdiv(tot, 256), 256, 0, st>>>(s->zq, s->zq_stride, s->frame, e->up_w, s->u0, B, C, st16);
-  }
+  GemmArgs a;
   const int M16 = B * st16;
 
   for (int l = 0; l < c.m_layers; ++l) {

@@ -1130,51 +1130,49 @@ __global__ void prep_lm_kernel(const float *lat_in, const float *bos, const floa
   if (m < B) *(f32x4 *)(lat + (size_t)m * ldim + k) = z;
 }
 
-// Mimi input: latent * emb_std + emb_mean (reference tts_model.py:449) to FM
-__global__ void prep_mimi_kernel(const float *lat, const float *std, const float *mean, float *z_fm, int B, int ldim,
-                                 int MT, int nb_prep, RopeArgs rope) {
-  if ((int)blockIdx.x >= nb_prep) {  // the frame's RoPE table rides along (see prep_lm_kernel)
-    rope_table_entry(rope, (blockIdx.x - nb_prep) * blockDim.x + threadIdx.x);
+// Codec frame prologue in one launch (blocks < nb_main; the frame's RoPE table rides along in the remaining blocks):
+//   z = latent * emb_std + emb_mean                                  (reference tts_model.py:449)
+//   zq = quantizer.output_proj(z), a 1x1 conv ldim -> C, no bias     (dummy_quantizer.py:17-18)
+//   depthwise ConvTranspose1d k = 2s, stride s on that one input step (resample.py:40-51, conv.py:151-163):
+//     out[b, t, c] = zq[b, c] w[c, t] + zq_prev[b, c] w[c, s + t]
+// zq is double-buffered by frame parity (FM layout, one row per sequence), so `partial` is never materialised.
+// The three tiny launches this replaces cost more in launch latency than in work.
+__global__ void mimi_prologue_kernel(const float *lat, const float *std, const float *mean, const float *wq,
+                                     const float *wup, float *zq, long zdstride, const int *par_p, float *out, int B,
+                                     int ldim, int C, int s, int nb_main, RopeArgs rope) {
+  if ((int)blockIdx.x >= nb_main) {
+    rope_table_entry(rope, (blockIdx.x - nb_main) * blockDim.x + threadIdx.x);
     return;
   }
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  int KF = ldim / 16;
-  if (i >= MT * KF * 64) return;
-  int lane = i & 63;
-  int f = i >> 6;
-  int kf = f % KF, mt = f / KF;
-  int m = 16 * mt + (lane & 15);
-  int k = 16 * kf + 4 * (lane >> 4);
-  f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (m < B) v = *(const f32x4 *)(lat + (size_t)m * ldim + k) * *(const f32x4 *)(std + k) + *(const f32x4 *)(mean + k);
-  *(f32x4 *)(z_fm + (size_t)i * 4) = v;
-}
-
-// Depthwise ConvTranspose1d k = 2s, stride s on one input step per frame (reference resample.py:40-51,
-// conv.py:151-163): out[b, t, c] = z[b, c] w[c, t] + z_prev[b, c] w[c, s + t].  z is double-buffered by
-// frame parity, so `partial` never has to be materialised.
-__global__ void upsample_kernel(const float *zq, long zdstride, const int *par_p, const float *w, float *out, int B,
-                                int C, int s) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  int C4 = C / 4;
-  long total = (long)B * s * C4;
-  if (i >= total) return;
-  int c = (i % C4) * 4;
-  long r = i / C4;
-  int t = r % s;
-  int b = r / s;
-  int par = *par_p & 1;
-  int CF = C / 16;
-  size_t zi = (((size_t)(b >> 4) * CF + (c >> 4)) * 64 + 16 * ((c & 15) >> 2) + (b & 15)) * 4;
-  f32x4 zc = *(const f32x4 *)(zq + par * zdstride + zi);
-  f32x4 zp = *(const f32x4 *)(zq + (par ^ 1) * zdstride + zi);
-  f32x4 o;
+  // thread = (sequence b, 4 channels c, output step t), t fastest: the s threads of one (b, c) recompute the same
+  // 4 x ldim dot products from broadcast loads (cheaper than a second phase) and write s adjacent 16-byte outputs
+  const int C4 = C / 4, CF = C / 16;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * C4 * s) return;
+  const int t = (int)(i % s);
+  const int c = (int)((i / s) % C4) * 4, b = (int)(i / ((long)s * C4));
+  const int par = *par_p & 1;
+  f32x4 zc = {0.f, 0.f, 0.f, 0.f};
+  const float *lr = lat + (size_t)b * ldim;
+  for (int k = 0; k < ldim; k += 4) {
+    const f32x4 z = *(const f32x4 *)(lr + k) * *(const f32x4 *)(std + k) + *(const f32x4 *)(mean + k);
+    const f32x4 w0 = *(const f32x4 *)(wq + (size_t)(c + 0) * ldim + k), w1 = *(const f32x4 *)(wq + (size_t)(c + 1) * ldim + k);
+    const f32x4 w2 = *(const f32x4 *)(wq + (size_t)(c + 2) * ldim + k), w3 = *(const f32x4 *)(wq + (size_t)(c + 3) * ldim + k);
+    zc.x += (z.x * w0.x + z.y * w0.y) + (z.z * w0.z + z.w * w0.w);
+    zc.y += (z.x * w1.x + z.y * w1.y) + (z.z * w1.z + z.w * w1.w);
+    zc.z += (z.x * w2.x + z.y * w2.y) + (z.z * w2.z + z.w * w2.w);
+    zc.w += (z.x * w3.x + z.y * w3.y) + (z.z * w3.z + z.w * w3.w);
+  }
+  const size_t zi = (((size_t)(b >> 4) * CF + (c >> 4)) * 64 + 16 * ((c & 15) >> 2) + (b & 15)) * 4;
+  const f32x4 zp = *(const f32x4 *)(zq + (par ^ 1) * zdstride + zi);
+  if (t == 0) *(f32x4 *)(zq + par * zdstride + zi) = zc;  // next frame's zq_prev
   const int k2 = 2 * s;
-  o.x = zc.x * w[(c + 0) * k2 + t] + zp.x * w[(c + 0) * k2 + s + t];
-  o.y = zc.y * w[(c + 1) * k2 + t] + zp.y * w[(c + 1) * k2 + s + t];
-  o.z = zc.z * w[(c + 2) * k2 + t] + zp.z * w[(c + 2) * k2 + s + t];
-  o.w = zc.w * w[(c + 3) * k2 + t] + zp.w * w[(c + 3) * k2 + s + t];
-  long m = (long)b * s + t;
+  f32x4 o;
+  o.x = zc.x * wup[(c + 0) * k2 + t] + zp.x * wup[(c + 0) * k2 + s + t];
+  o.y = zc.y * wup[(c + 1) * k2 + t] + zp.y * wup[(c + 1) * k2 + s + t];
+  o.z = zc.z * wup[(c + 2) * k2 + t] + zp.z * wup[(c + 2) * k2 + s + t];
+  o.w = zc.w * wup[(c + 3) * k2 + t] + zp.w * wup[(c + 3) * k2 + s + t];
+  const long m = (long)b * s + t;
   *(f32x4 *)(out + (((size_t)(m >> 4) * CF + (c >> 4)) * 64 + 16 * ((c & 15) >> 2) + (m & 15)) * 4) = o;
 }
 
