@@ -1,30 +1,35 @@
 #!/usr/bin/env python3
 """Benchmark of the Pocket-TTS decode hot path on MI355X (metric: BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--preset headline|config4|b1|int8]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A *step* is one 80 ms frame of every utterance of the batch: one FlowLM autoregressive step plus one
-Mimi codec decode for `--batch` (default 64) concurrent fixed-length utterances per GPU
-(BASELINE.json configs[2]).  A *job* is one batch of 10 s utterances: voice-state
-clone + text prefill (32 tokens) + 125 steps; all of it sits inside the timed region, with inputs
-(weights, voice KV, token ids) resident in HBM.  Each rank runs the same work on its own GPU
-(utterances are independent: no collective on the data path), so scaling is "weak".
+A *step* is one 80 ms frame of every utterance of the batch: one FlowLM autoregressive step plus one Mimi codec
+decode for `--batch` (default 64) concurrent fixed-length utterances per GPU (BASELINE.json configs[2]; SURVEY.md
+section 8d).  An *utterance job* is: voice-state clone + text prefill (32 tokens) + 125 steps (10 s of audio).  The
+timed region always STARTS at an utterance boundary, so the clone and the prefill are inside it whatever K is; with the
+default K = 125 it is exactly one whole job.  Inputs (weights, voice KV, token ids) are resident in HBM; every PCM chunk
+lands in pinned host memory inside the timed region.
 
-Weights are synthetic (seed 0), data synthetic; fp32 end to end like the reference.
-One JSON line is printed by rank 0.
+`--gpus N` without a launcher starts N fresh worker processes itself (before the parent touches any GPU), one engine
+per GPU, rendezvous on 127.0.0.1; under `torch.distributed.run` the ranks it is given are used.  Utterances are
+independent: each rank runs the same work on its own GPU, RCCL carries only the barriers and a few scalars, scaling is
+"weak".  Presets: `config4` = 24-layer model, 32 utterances per GPU (BASELINE.json configs[3], meant for --gpus 8);
+`b1` = batch 1; `int8` = configs[4] first half (int8 LM weights), a separate line, never the headline.
+
+Weights are synthetic (seed 0), data synthetic; fp32 end to end like the reference.  Rank 0 prints ONE JSON line.
 """
 
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
@@ -32,15 +37,23 @@ sys.path.insert(0, REPO)
 FRAME_S = 0.08
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+MIMI_MAC_PER_FRAME = 271e6  # Mimi decode, MACs per sequence and frame (same codec in every config)
+PRESETS = {
+    "headline": {},
+    "config4": dict(config="24l", batch=32),
+    "b1": dict(batch=1),
+    "int8": dict(quantize=True),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=125)
     ap.add_argument("--warmup", type=int, default=25)
-    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
-    ap.add_argument("--config", default="en100m", choices=["en100m", "24l", "tiny"])
+    ap.add_argument("--preset", choices=sorted(PRESETS), default="headline")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default 64)")
+    ap.add_argument("--config", default=None, choices=["en100m", "24l", "tiny"])
     ap.add_argument("--voice-len", type=int, default=126)
     ap.add_argument("--text-len", type=int, default=32)
     ap.add_argument("--frames", type=int, default=125, help="frames per utterance (10 s)")
@@ -48,17 +61,49 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--quantize", action="store_true",
-                    help="BASELINE config #5: int8 weights for the FlowLM attention + FFN layers (not the headline: "
-                         "the default run is the fp32 path whose parity is pinned)")
-    ap.add_argument("--cpu-steps", type=int, default=8)
-    return ap.parse_args()
+    ap.add_argument("--quantize", action="store_true", default=None,
+                    help="BASELINE config #5: int8 weights for the FlowLM attention + FFN layers (not the headline)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the cpu_baseline leg")
+    ap.add_argument("--latency-trials", type=int, default=200)
+    args = ap.parse_args(argv)
+    for k, v in PRESETS[args.preset].items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    args.batch = 64 if args.batch is None else args.batch
+    args.config = args.config or "en100m"
+    args.quantize = bool(args.quantize)
+    return args
+
+
+# --------------------------------------------------------------------------------------------------------------
+# --gpus N without a launcher: the parent spawns the ranks (it has not touched a GPU: no re-exec of a GPU process)
+def spawn_ranks(n: int) -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for r, p in enumerate(procs):
+        c = p.wait()
+        if c != 0:
+            print(f"bench.py: rank {r} exited with code {c}", file=sys.stderr)
+            rc = rc or c or 1
+    return rc
 
 
 class Job:
     """Fixed-length synthetic utterance batch on one GPU, hipGraph per step."""
 
     def __init__(self, eng, B, args, seed):
+        import torch
+
+        from pocket_tts_amd.engine import StepPipeline
+
         self.eng, self.B, self.args = eng, B, args
         cfg = eng.cfg
         dev = eng.device
@@ -75,10 +120,9 @@ class Job:
         self.ms = eng.new_mimi_state(B)
         self.st.set_noise(args.temp, 1234 + seed)
         # EOS stop disabled (threshold +inf) so every utterance has exactly `frames` frames
-        from pocket_tts_amd.engine import StepPipeline
-
         self.pipe = StepPipeline(eng, self.st, self.ms, None, 1, float("inf"))
         self.frame = args.frames  # forces a (re)start on the first step
+        self.contexts = []        # FlowLM context (keys attended) of every step since reset_log()
 
     def start_utterances(self):
         eng = self.eng
@@ -92,6 +136,7 @@ class Job:
         if self.frame >= self.args.frames:
             self.start_utterances()
         self.pipe.step()
+        self.contexts.append(self.args.voice_len + self.args.text_len + self.frame + 1)
         self.frame += 1
         if self.frame >= self.args.frames:
             self.pipe.flush()  # the utterances' last frame has no FlowLM step to ride along with
@@ -100,45 +145,82 @@ class Job:
         self.pipe.sync()
 
 
-def first_chunk_latency(eng, args, trials=200):  # 200 trials: SURVEY 8(d)
-    """B=1 streaming path (BASELINE.json configs[1]): time from request (voice state resident) to the
-    first 80 ms PCM chunk on the host = state clone + text prefill + 1 LM step + 1 Mimi frame + D2H."""
-    B = 1
-    a = argparse.Namespace(**vars(args))
-    job = Job(eng, B, a, seed=7)
-    lat_ms = []
-    for t in range(trials + 5):
-        job.sync()
+class _CharTokenizer:
+    """Stand-in tokenizer for the synthetic model (no sentencepiece model of vocabulary n_bins exists offline): one id
+    per character behind a leading marker token, invertible, so the reference's sentence splitting works unchanged."""
+
+    def __init__(self, n_bins):
+        self.n_bins, self.sp = n_bins, self
+
+    def encode(self, text):
+        return [self.n_bins - 1] + [ord(c) % (self.n_bins - 1) for c in text]
+
+    def decode(self, ids):
+        return "".join(chr(i) for i in ids if i != self.n_bins - 1)
+
+
+def first_chunk_latency(eng, args, job1):
+    """B=1 streaming path (BASELINE.json configs[1]) measured THROUGH the drop-in API: time from the
+    `TTSModel.generate_audio_stream()` call (voice state resident) to the first [1920] chunk on the host = state clone +
+    text prefill + FlowLM step + Mimi frame + D2H.  Also: the same at engine level, and the steady-state step time."""
+    import numpy as np
+
+    from pocket_tts_amd.tts_model import TTSModel, _export_lm_state
+
+    cfg = eng.cfg
+    model = TTSModel(eng, cfg, _CharTokenizer(cfg.flow_lm.lookup_table.n_bins), args.temp, 1, None, float("inf"))
+    voice_state = _export_lm_state(eng, job1.voice, args.voice_len)  # reference-format dict, as a caller holds it
+    text = "The quick brown fox jumps over."  # 31 characters + marker = 32 tokens
+    assert len(model.tokenizer.encode(text)) == args.text_len or args.text_len != 32
+    api_ms = []
+    for t in range(args.latency_trials + 5):
         eng.sync()
         t0 = time.perf_counter()
-        job.start_utterances()
-        job.pipe.step()
-        job.pipe.flush()
-        job.sync()
+        gen = model.generate_audio_stream(voice_state, text)
+        chunk = next(gen)
+        dt = (time.perf_counter() - t0) * 1e3
+        gen.close()
+        assert chunk.shape[0] == eng.frame_samples
+        if t >= 5:
+            api_ms.append(dt)
+    eng_ms = []
+    for t in range(args.latency_trials // 4 + 5):
+        job1.sync()
+        eng.sync()
+        t0 = time.perf_counter()
+        job1.start_utterances()
+        job1.pipe.step()
+        f = job1.pipe.flush()
+        job1.pipe.ev[f & 1].synchronize()
         dt = (time.perf_counter() - t0) * 1e3
         if t >= 5:
-            lat_ms.append(dt)
-    # steady-state per-step time of the B=1 pipeline (one full utterance)
-    job.start_utterances()
+            eng_ms.append(dt)
+    # steady-state per-step time of the B=1 pipeline
+    job1.start_utterances()
     for _ in range(20):
-        job.step()
-    job.sync()
+        job1.step()
+    job1.sync()
     n = 100
     t0 = time.perf_counter()
     for _ in range(n):
-        job.step()
-    job.sync()
+        job1.step()
+    job1.sync()
     per_step_ms = (time.perf_counter() - t0) * 1e3 / n
-    return dict(first_chunk_ms_p50=float(np.percentile(lat_ms, 50)), first_chunk_ms_p99=float(np.percentile(lat_ms, 99)),
-                b1_ms_per_step=per_step_ms, b1_xrt=FRAME_S * 1e3 / per_step_ms, trials=trials)
+    return dict(first_chunk_ms_p50=float(np.percentile(api_ms, 50)), first_chunk_ms_p99=float(np.percentile(api_ms, 99)),
+                measured_through="TTSModel.generate_audio_stream()", trials=args.latency_trials,
+                engine_level_first_chunk_ms_p50=float(np.percentile(eng_ms, 50)),
+                b1_ms_per_step=per_step_ms, b1_xrt=FRAME_S * 1e3 / per_step_ms)
 
 
 def kernel_profile(eng, job, nsteps=6):
     """A few eager (non-graph) steps with per-launch HIP events on the launch stream."""
+    import torch
+
     job.start_utterances()
     for _ in range(40):  # mid-utterance context
         job.step()
     eng.sync()
+    ctx = job.contexts[-1] + 1
     eng.profile_start()
     job.pipe.flush()
     job.sync()
@@ -154,90 +236,146 @@ def kernel_profile(eng, job, nsteps=6):
         k = per_kernel.setdefault(r["kernel"], dict(count=0, total_ms=0.0, bytes=0.0, flops=0.0))
         for f in ("count", "total_ms", "bytes", "flops"):
             k[f] += r[f]
-    return rows, per_kernel, nsteps
+    return rows, per_kernel, nsteps, ctx
 
 
-def pmc_traffic(name):
-    """HBM bytes per launch of `name` from the committed PMC passes (profiles/r01_pmc_traffic.json: rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 calibration); None if that
-    kernel was not profiled.  PMC counters cannot be read from inside this process."""
+def tune_table_id(eng) -> str:
+    """identifies the tile table the kernels of this run were chosen from (stamped into PMC files and bench lines)"""
+    return hashlib.sha256("\n".join(sorted(eng._tune_table())).encode()).hexdigest()[:12]
+
+
+def pmc_traffic(name, table_id):
+    """HBM bytes per launch of `name` from the committed PMC passes (profiles/r02_pmc_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 calibration).  PMC counters cannot be
+    read from inside this process, so the file is a replay; it is only used when it was measured on the SAME tile
+    table as this run (its `tune_table_id` stamp), else None."""
     try:
-        with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as f:
-            return json.load(f)["kernels"][name]["traffic_bytes_per_launch"]
+        with open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")) as f:
+            d = json.load(f)
+        if d.get("tune_table_id") != table_id:
+            return None
+        return d["kernels"][name]["traffic_bytes_per_launch"]
     except Exception:
         return None
 
 
-def roofline_of(per_kernel):
+def roofline_of(per_kernel, table_id):
     name, k = max(per_kernel.items(), key=lambda kv: kv[1]["total_ms"])
     avg_s = k["total_ms"] / k["count"] * 1e-3
     gbs = k["bytes"] / k["count"] / avg_s / 1e9
     tfs = k["flops"] / k["count"] / avg_s / 1e12
+    common = dict(kernel=name, traffic=pmc_traffic(name, table_id), avg_us=avg_s * 1e6, launches=k["count"],
+                  algorithmic_bytes_per_launch=k["bytes"] / k["count"], flops_per_launch=k["flops"] / k["count"],
+                  timing="HIP events around each launch on its own stream (eager steps at mid-utterance context)")
     if tfs / MFMA_F32_PEAK_TF > gbs / HBM_PEAK_GBS:
-        return dict(kernel=name, bound="mfma", achieved=tfs, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                    frac=tfs / MFMA_F32_PEAK_TF, traffic=pmc_traffic(name), avg_us=avg_s * 1e6, launches=k["count"],
-                    algorithmic_bytes_per_launch=k["bytes"] / k["count"], flops_per_launch=k["flops"] / k["count"])
-    return dict(kernel=name, bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                traffic=pmc_traffic(name), avg_us=avg_s * 1e6, launches=k["count"],
-                algorithmic_bytes_per_launch=k["bytes"] / k["count"], flops_per_launch=k["flops"] / k["count"])
+        return dict(bound="mfma", achieved=tfs, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=tfs / MFMA_F32_PEAK_TF, **common)
+    return dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, **common)
 
 
-def cpu_baseline(args, cfg, W, nsteps):
-    """The numpy oracle (a port of the reference algorithm, see oracle/np_oracle.py) timed on the
-    host cores for a bounded sample of the same workload."""
-    from oracle import np_oracle as O
+def cpu_baseline(args, cfg, W):
+    """The CPU restatement of the path on stock PyTorch CPU operators (oracle/torch_oracle.py, pinned to the reference's
+    golden vectors by tests/test_torch_oracle.py), timed on this box's host cores for a bounded sample of the same
+    workload: (ii) the benchmark's batch on all host cores -> `value`; (i) the reference's own operating
+    point: batch 1, torch.set_num_threads(1), FlowLM and Mimi pipelined on two threads (tts_model.py:49,651-658)."""
+    import queue
+    import threading
+
+    import torch
+
+    from oracle import torch_oracle as O
 
     B = args.batch
     lm, dec = O.FlowLM(cfg, W), O.MimiDecoder(cfg, W)
-    rng = np.random.default_rng(1)
-    st = lm.init_state(B, args.voice_len + args.text_len + nsteps + 1)
-    lm.prefill(st, np.repeat((rng.standard_normal((1, args.voice_len, lm.D)) * 0.1).astype(np.float32), B, 0))
-    lm.prefill(st, lm.embed_text(rng.integers(0, cfg.flow_lm.lookup_table.n_bins, (B, args.text_len))))
-    ms = dec.init_state(B, nsteps)
-    x = np.full((B, lm.ldim), np.nan, np.float32)
-    t0 = time.perf_counter()
-    for _ in range(nsteps):
-        noise = (rng.standard_normal((B, lm.ldim)) * args.temp ** 0.5).astype(np.float32)
+    g = torch.Generator().manual_seed(1)
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(min(ncores, 64))  # ATen's intra-op pool; more threads than ~64 only add contention
+    used = torch.get_num_threads()
+
+    def prefilled(b, nsteps):
+        st = lm.init_state(b, args.voice_len + args.text_len + nsteps + 1)
+        lm.prefill(st, (torch.randn(1, args.voice_len, lm.D, generator=g) * 0.1).expand(b, -1, -1))
+        lm.prefill(st, lm.embed_text(torch.randint(0, cfg.flow_lm.lookup_table.n_bins, (b, args.text_len), generator=g)))
+        return st
+
+    # (ii) batch B, all cores: one warm step, then as many steps as fit the budget
+    nmax = 64
+    st, ms = prefilled(B, nmax), dec.init_state(B, nmax)
+    x = torch.full((B, lm.ldim), float("nan"))
+    budget = args.cpu_seconds * 0.6
+    n, t0 = 0, None
+    for i in range(nmax):
+        if i == 1:
+            t0 = time.perf_counter()
+        noise = torch.randn(B, lm.ldim, generator=g) * args.temp ** 0.5
         x, _, _ = lm.decode_step(st, x, noise, 1, float("inf"))
         dec.decode(ms, x)
+        if i >= 1:
+            n += 1
+            if time.perf_counter() - t0 > budget:
+                break
     dt = time.perf_counter() - t0
-    out = dict(value=B * nsteps * FRAME_S / dt, unit="audio-seconds/sec", cores=os.cpu_count(), kind="port",
-               sample=f"{nsteps} decode steps (LM + Mimi) of batch {B} after voice+text prefill, numpy/BLAS oracle, "
-                      f"{dt:.1f} s wall")
-    # the reference's own operating point (SURVEY 8d setting (i)): batch 1, one BLAS thread (torch.set_num_threads(1),
-    # tts_model.py:49); LM step and codec frame timed back to back, i.e. without the reference's two-thread overlap
-    try:
-        from threadpoolctl import threadpool_limits
+    out = dict(value=B * n * FRAME_S / dt, unit="audio-seconds/sec", cores=used, kind="port",
+               sample=f"{n} decode steps (FlowLM + Mimi) of batch {B} after voice+text prefill, torch {torch.__version__} CPU "
+                      f"operators with {used} intra-op threads on a {ncores}-thread host, {dt:.1f} s wall")
+    # (i) batch 1, one intra-op thread per stage, two pipeline threads like the reference
+    torch.set_num_threads(1)
+    st1, ms1 = prefilled(1, nmax), dec.init_state(1, nmax)
+    q: queue.Queue = queue.Queue()
+    done = []
 
-        with threadpool_limits(limits=1):
-            st1 = lm.init_state(1, args.voice_len + args.text_len + 9)
-            lm.prefill(st1, (rng.standard_normal((1, args.voice_len + args.text_len, lm.D)) * 0.1).astype(np.float32))
-            ms1 = dec.init_state(1, 8)
-            x1 = np.full((1, lm.ldim), np.nan, np.float32)
-            t1 = time.perf_counter()
-            for _ in range(8):
-                x1, _, _ = lm.decode_step(st1, x1, None, 1, float("inf"))
-                dec.decode(ms1, x1)
-            d1 = time.perf_counter() - t1
-        out["batch1_one_thread"] = dict(value=8 * FRAME_S / d1, unit="audio-seconds/sec", cores=1,
-                                        sample=f"8 decode steps (LM + Mimi) of batch 1, one BLAS thread, {d1:.2f} s wall")
-    except Exception as e:  # threadpoolctl missing: report only the all-cores figure
-        out["batch1_one_thread"] = dict(error=str(e))
+    def codec():
+        torch.set_num_threads(1)
+        while True:
+            z = q.get()
+            if z is None:
+                return
+            dec.decode(ms1, z)
+            done.append(time.perf_counter())
+
+    th = threading.Thread(target=codec)
+    th.start()
+    x1 = torch.full((1, lm.ldim), float("nan"))
+    budget1 = args.cpu_seconds * 0.4
+    t1 = time.perf_counter()
+    n1 = 0
+    for i in range(nmax):
+        x1, _, _ = lm.decode_step(st1, x1, torch.randn(1, lm.ldim, generator=g) * args.temp ** 0.5, 1, float("inf"))
+        q.put(x1)
+        n1 += 1
+        if time.perf_counter() - t1 > budget1:
+            break
+    q.put(None)
+    th.join()
+    d1 = done[-1] - t1
+    out["batch1_reference_setting"] = dict(
+        value=n1 * FRAME_S / d1, unit="audio-seconds/sec", cores=2,
+        sample=f"{n1} frames of batch 1, torch.set_num_threads(1), FlowLM thread -> queue -> Mimi thread "
+               f"(reference tts_model.py:49,651-658), {d1:.1f} s wall")
+    torch.set_num_threads(used)
     return out
 
 
 def main():
     args = parse()
-    # Tile choices are pinned to the table measured on an MI355X and committed with the profiles, so that the kernel
-    # names in this run, in profiles/*_kernel_stats.csv and in profiles/*_pmc_traffic.json refer to the same
-    # configurations (the autotuner's near-ties otherwise flip between runs).  Shapes missing from the table are
-    # tuned live and appended; PTTS_TUNE_CACHE= (empty) tunes everything live.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    import numpy as np
+    import torch
+
+    # Tile choices come from the table measured on an MI355X and committed with the profiles (so kernel names in this
+    # run, in profiles/*_kernel_stats.csv and in profiles/*_pmc_traffic.json mean the same configurations); shapes
+    # missing from it are tuned live and written to an UNTRACKED file.  PTTS_TUNE_CACHE= (empty) tunes everything live.
     os.environ.setdefault("PTTS_TUNE_CACHE", os.path.join(REPO, "profiles", "tune_cache_mi355x.txt"))
     if not os.environ["PTTS_TUNE_CACHE"]:
         del os.environ["PTTS_TUNE_CACHE"]
+    scratch = os.path.join(REPO, "gpurun_out")
+    os.makedirs(scratch, exist_ok=True)
     from pocket_tts_amd import parallel
 
     rank, local, world = parallel.env_ranks()
+    os.environ.setdefault("PTTS_TUNE_CACHE_OUT", os.path.join(scratch, f"tune_additions_rank{rank}.txt"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using the launcher's world size", file=sys.stderr)
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     dist = parallel.init_distributed("nccl", dev)  # RCCL; only barriers + scalar reductions
@@ -261,24 +399,35 @@ def main():
 
     for _ in range(args.warmup):
         job.step()
+    job.pipe.flush()
+    job.frame = args.frames  # the timed region starts at an utterance boundary: clone + prefill are inside it
+    job.contexts = []
     barrier()
     eng.timer_start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         job.step()
+    job.pipe.flush()
     job.sync()
     ev_ms = eng.timer_stop_ms()
     barrier()
-    wall = time.perf_counter() - t0
-    audio_total, wall = parallel.job_throughput(args.batch * args.steps * FRAME_S, wall, dist, dev)
-    audio_total *= wall  # job_throughput returns units/s; keep the totals explicit below
+    wall_rank = time.perf_counter() - t0
+    audio_rank = args.batch * args.steps * FRAME_S
+    rate, wall = parallel.job_throughput(audio_rank, wall_rank, dist, dev)
+    per_rank = [audio_rank / wall_rank]
+    if dist is not None:
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = per_rank[0]
+        dist.all_reduce(t)
+        per_rank = [float(v) for v in t.tolist()]
 
-    out = None
     if rank == 0:
-        audio_s = audio_total
+        L = cfg.flow_lm.transformer.num_layers
+        ctx = float(np.mean(job.contexts))
+        restarts = sum(1 for c in job.contexts if c == args.voice_len + args.text_len + 1)
         out = {
             "metric": "audio-seconds/sec (xRT), 100M en model, whole job over all GPUs",
-            "value": audio_s / wall,
+            "value": rate,
             "unit": "audio-seconds/sec",
             "n_gpus": world,
             "steps": args.steps,
@@ -293,25 +442,45 @@ def main():
                 "workload": f"{args.config}: batch {args.batch} concurrent utterances/GPU, voice KV {args.voice_len} + "
                             f"text {args.text_len} tokens, {args.frames} frames (10 s) each, temp {args.temp}, "
                             f"lsd_decode_steps 1; per utterance: state clone + text prefill + FlowLM step + Mimi "
-                            f"decode per frame, hipGraph per FlowLM step and per codec frame on two streams (step t+1 overlaps frame t), PCM written straight into pinned host memory",
+                            f"decode per frame, hipGraph per FlowLM step and per codec frame on two streams (step t+1 "
+                            f"overlaps frame t), PCM written straight into pinned host memory",
+                "preset": args.preset,
                 "batch_per_gpu": args.batch,
                 "parallelism": f"replicas x{world} (no collective on the data path)",
+                "timed_region": f"{args.steps} steps from an utterance boundary: {restarts} clone+prefill inside, "
+                                f"mean FlowLM context {ctx:.1f} keys",
             },
-            "xrt_per_gpu": audio_s / wall / world,
+            "xrt_per_gpu": rate / world,
+            "per_rank_xrt": per_rank,
             "stream_event_ms_per_step": ev_ms / args.steps,
+            "tune_table_id": tune_table_id(eng),
+        }
+        # whole-step bounds at the contexts actually timed (SURVEY 8d bytes_step / flops formulas)
+        bytes_step = (eng.lm_weight_bytes() + eng.mimi_weight_bytes()
+                      + args.batch * (8 * L * ctx * 1024 + 2.18e6 + 68e3))
+        lm_mac = eng.lm_weight_bytes() / (1.0 if args.quantize else 4.0)  # one MAC per weight and row (int8: ~1 B/weight)
+        flops_step = 2.0 * args.batch * (lm_mac + 2 * L * ctx * 1024 + MIMI_MAC_PER_FRAME)
+        step_s = wall / args.steps
+        out["step_roofline"] = {
+            "algorithmic_bytes_per_step": bytes_step, "hbm_bound_us_at_8TBs": bytes_step / 8e12 * 1e6,
+            "hbm_frac": bytes_step / 8e12 / step_s,
+            "algorithmic_flops_per_step": flops_step, "mfma_f32_bound_us": flops_step / (MFMA_F32_PEAK_TF * 1e12) * 1e6,
+            "mfma_frac": flops_step / (MFMA_F32_PEAK_TF * 1e12) / step_s,
+            "mean_context": ctx,
         }
         if not args.no_profile:
-            rows, per_kernel, nst = kernel_profile(eng, job)
-            out["roofline"] = roofline_of(per_kernel)
+            rows, per_kernel, nst, pctx = kernel_profile(eng, job)
+            tid = out["tune_table_id"]
+            out["roofline"] = roofline_of(per_kernel, tid)
+            out["roofline"]["context_keys"] = pctx
             tot = sum(r["total_ms"] for r in rows)
             out["kernel_ms_per_step"] = {k: round(v["total_ms"] / nst, 4) for k, v in
                                          sorted(per_kernel.items(), key=lambda kv: -kv[1]["total_ms"])}
             out["kernel_sum_ms_per_step"] = tot / nst
             # per label: [algorithmic MB per launch, HBM-side MB per launch from the committed PMC passes or null]
             out["kernel_mb_per_launch"] = {k: [round(v["bytes"] / v["count"] / 1e6, 2),
-                                               (lambda t: None if t is None else round(t / 1e6, 2))(pmc_traffic(k))]
+                                               (lambda t: None if t is None else round(t / 1e6, 2))(pmc_traffic(k, tid))]
                                            for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["total_ms"])}
-            # the same events grouped by call site (lm.qkv, seanet.convtr2, ...): us per launch, launches per step
             sites = {}
             for r in rows:
                 k = sites.setdefault(r["site"] + " " + r["kernel"], [0, 0.0])
@@ -319,18 +488,13 @@ def main():
                 k[1] += r["total_ms"]
             out["site_us_per_launch"] = {k: [round(v[1] / v[0] * 1e3, 2), round(v[0] / nst, 2)]
                                          for k, v in sorted(sites.items(), key=lambda kv: -kv[1][1])}
-            # whole-step achieved fraction of the HBM roofline (SURVEY 8d bytes_step formula)
-            ctx = args.voice_len + args.text_len + args.frames / 2
-            L = cfg.flow_lm.transformer.num_layers
-            bytes_step = (eng.lm_weight_bytes() + eng.mimi_weight_bytes()
-                          + args.batch * (8 * L * ctx * 1024 + 2.18e6 + 68e3))
-            out["step_hbm_roofline"] = {"algorithmic_bytes_per_step": bytes_step,
-                                        "bound_us_at_8TBs": bytes_step / 8e12 * 1e6,
-                                        "frac": bytes_step / 8e12 / (wall / args.steps)}
         if not args.no_latency and world == 1:
-            out["latency_b1"] = first_chunk_latency(eng, args)
+            a1 = argparse.Namespace(**vars(args))
+            job1 = Job(eng, 1, a1, seed=7)
+            out["latency_b1"] = first_chunk_latency(eng, a1, job1)
+            job1 = None
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args, cfg, W, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(args, cfg, W)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

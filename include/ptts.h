@@ -7,8 +7,16 @@
  * pointers to fp32 data (e.g. torch `tensor.data_ptr()` on a ROCm device); `h_*` are host
  * pointers.  `stream` is a `hipStream_t` passed as `void*` (NULL = the engine's own
  * stream).  Every function returns 0 on success or a negative error code;
- * `ptts_last_error()` returns the message.  No exceptions cross the ABI.  Handles are not
- * re-entrant: one thread per handle at a time.
+ * `ptts_last_error()` returns the message (per calling thread).  No exceptions cross the ABI.
+ *
+ * Threading contract.  The library keeps NO process-global mutable state: profiler, tile table, LSD tables and the
+ * allocation stream live in the engine or in the calling thread.  Engines are independent: any number of engines
+ * (one per GPU, or several on one GPU) may be driven from different threads at the same time.  Entry points that
+ * enqueue work on an engine serialise on that engine's mutex, so two threads MAY share one engine (e.g. a batching
+ * scheduler thread and a request thread); device-side ordering between their calls is the caller's business
+ * (streams / events).  A state or graph handle is not re-entrant: one thread per ptts_lm_state / ptts_mimi_state /
+ * ptts_graph at a time.  At most ~8 decode steps of different states of one GPU should be in flight at once: the
+ * single-launch flow MLP (ptts_set_option "flow_cluster") needs all its workgroups resident together.
  */
 #ifndef PTTS_H_
 #define PTTS_H_
@@ -159,9 +167,21 @@ void ptts_tune_clear(ptts_engine *e);
 /* The tuned table as text (one line per GEMM shape) so that a deployment tunes once: export after ptts_tune,
  * import (returns the number of entries accepted) before capturing graphs in a later process. */
 int64_t ptts_tune_export(ptts_engine *e, char *h_out, int64_t capacity);
+/* version of the table format + configuration list: a cache file written by another version must not be imported */
+int ptts_tune_version(void);
 int ptts_tune_import(ptts_engine *e, const char *text);
 
 /* ---- utilities */
+/* Engine options (experiments / A-B tests; defaults come from the environment variable in brackets):
+ *   "flow_cluster"  [PTTS_FLOW_CLUSTER, 1]  1 = the flow MLP of a decode step runs as ONE cooperative launch
+ *                                           (ptts_flow.h), 0 = one GEMM launch per layer
+ *   "k_rotate"      [PTTS_K_ROTATE, 1]      1 = K-split GEMM workgroups start their K loop at a column-block dependent
+ *                                           chunk (spreads the re-reads of the shared activation rows over L2 channels)
+ * Applies to steps enqueued / graphs captured after the call.  Returns -1 for an unknown key. */
+int ptts_set_option(ptts_engine *e, const char *key, int32_t value);
+/* 1 after a cooperative kernel of this state gave up waiting for a peer workgroup (its outputs are then invalid);
+ * synchronises the stream.  Never 1 unless the GPU was oversubscribed beyond the contract above. */
+int ptts_lm_state_error(ptts_lm_state *s, void *stream);
 int ptts_sync(ptts_engine *e, void *stream);
 void *ptts_engine_stream(ptts_engine *e);
 /* asynchronous device -> pinned-host copy on `stream` (PCM chunks, EOS flags) */

@@ -77,6 +77,9 @@ PROTOTYPES = {
     "ptts_tune_clear": (None, [_P]),
     "ptts_tune_export": (C.c_int64, [_P, C.c_char_p, C.c_int64]),
     "ptts_tune_import": (C.c_int, [_P, C.c_char_p]),
+    "ptts_tune_version": (C.c_int, []),
+    "ptts_set_option": (C.c_int, [_P, C.c_char_p, C.c_int32]),
+    "ptts_lm_state_error": (C.c_int, [_P, _P]),
     "ptts_sync": (C.c_int, [_P, _P]),
     "ptts_engine_stream": (_P, [_P]),
     "ptts_copy_to_host_async": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
@@ -91,7 +94,7 @@ PROTOTYPES = {
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile csrc/ptts.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    deps = [SRC, SRC.parent / "ptts_kernels.h", HEADER]
+    deps = [SRC, *sorted(SRC.parent.glob("*.h")), HEADER]
     if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -111,6 +111,9 @@ class ContinuousBatcher:
         self._thread = None
         self._stop = False
         self._chain: dict = {}  # request id -> deque of follow-up chunks (run one after the other)
+        self._outstanding: dict = {}  # request id -> Request, from submit() until its final sentinel: what _fail / stop notify
+        self._failed: Exception | None = None
+        self._closed = False
 
     # ---- submission (any thread) ---------------------------------------------------------------
     def submit(self, model_state: dict, text: str, frames_after_eos: int | None = None, max_tokens: int = 50) -> Request:
@@ -119,6 +122,8 @@ class ContinuousBatcher:
         from .tts_model import _state_current_end
 
         m = self.model
+        if self._failed is not None:
+            raise RuntimeError(f"the batcher has stopped after an error: {self._failed}")
         if not text or not text.strip():
             raise ValueError("Text to generate cannot be empty")
         chunks = split_into_best_sentences(m.tokenizer.encode, m.tokenizer.sp, text, max_tokens,
@@ -139,6 +144,10 @@ class ContinuousBatcher:
             jobs.append(_Job(req, torch.tensor(ids, dtype=torch.long)[None, :], model_state, gen, fae, i == len(chunks) - 1))
         req._pending_chunks = len(jobs)
         with self._wake:
+            if self._failed is not None or self._closed:
+                raise RuntimeError("the batcher is closed" if self._failed is None else
+                                   f"the batcher has stopped after an error: {self._failed}")
+            self._outstanding[req.id] = req
             self.waiting.append(jobs[0])
             if len(jobs) > 1:
                 self._chain[req.id] = collections.deque(jobs[1:])
@@ -147,7 +156,7 @@ class ContinuousBatcher:
 
     # ---- scheduler (one thread) ----------------------------------------------------------------
     def _admit(self):
-        from .tts_model import _import_lm_state, _state_current_end
+        from .tts_model import _state_current_end
 
         eng = self.eng
         while True:
@@ -157,21 +166,38 @@ class ContinuousBatcher:
                     return
                 job = self.waiting.popleft()
             b = free[0]
-            t_voice = _state_current_end(job.voice)
-            Tt = job.tokens.shape[1]
-            one = eng.new_lm_state(1, t_voice + Tt)
+            one = None
             try:
-                _import_lm_state(eng, one, job.voice, t_voice)
+                t_voice = _state_current_end(job.voice)
+                Tt = job.tokens.shape[1]
+                one = eng.new_lm_state(1, t_voice + Tt)
+                one.copy_from(self.model._voice_lm_state(job.voice, t_voice))  # device-resident voice, no host sync
                 eng.lm_prefill(one, eng.embed_text(job.tokens))
                 self.st.copy_row_from(b, one)       # KV rows, position, BOS as the pending input, row active
                 eng.sync()
+            except (ValueError, KeyError, IndexError, TypeError) as e:
+                # a bad request (malformed voice state, capacity): fail THIS request, keep serving the others.  The job
+                # is in no list any more, so it is notified here (its consumer used to block forever).
+                self._end_request(job.req, e)
+                continue
             finally:
-                one.close()
+                if one is not None:
+                    one.close()
             # the slot's codec carries: zero on the codec stream, behind the frames already queued there
             self.ms.reset_row(b, self.pipe.s2)
             job.start = self.g
             self.slot[b] = job
             self.history[b].append(job)
+
+    def _end_request(self, req, error: Exception | None = None):
+        """final sentinel of a request (with `error`: the consumer's iteration raises it); drops its follow-up chunks"""
+        with self._wake:
+            if self._outstanding.pop(req.id, None) is None:
+                return
+            self._chain.pop(req.id, None)
+        if error is not None:
+            req.error = error
+        req._q.put(None)
 
     def _route(self, frame: int):
         """hand the rows of decoded `frame` to their requests"""
@@ -207,6 +233,7 @@ class ContinuousBatcher:
                             if not nxt:
                                 del self._chain[req.id]
                         elif req._pending_chunks == 0:
+                            self._outstanding.pop(req.id, None)
                             req._q.put(None)
 
     def step(self) -> bool:
@@ -273,11 +300,15 @@ class ContinuousBatcher:
         self._thread.start()
 
     def _fail(self, e: Exception):
+        """the scheduler cannot continue: every outstanding request - waiting, admitted or mid-admission - gets the
+        error, and later submit() calls raise"""
         logger.error("batcher failed: %s", e)
-        reqs = {j.req for h in self.history for j in h if j.req is not None} | {j.req for j in self.waiting}
+        with self._wake:
+            self._failed = e
+            reqs = list(self._outstanding.values())
+            self.waiting.clear()
         for r in reqs:
-            r.error = e
-            r._q.put(None)
+            self._end_request(r, e)
 
     def stop(self):
         with self._wake:
@@ -288,7 +319,14 @@ class ContinuousBatcher:
             self._thread = None
 
     def close(self):
+        """stops the scheduler; requests still outstanding receive an error instead of blocking their consumers"""
         self.stop()
+        with self._wake:
+            self._closed = True
+            reqs = list(self._outstanding.values())
+            self.waiting.clear()
+        for r in reqs:
+            self._end_request(r, RuntimeError("the batcher was closed before this request finished"))
         self.pipe.sync()
         self.pipe.close()
         self.st.close()

@@ -1,6 +1,7 @@
 // Host side of libptts: engine construction (weight packing), FlowLM / Mimi step orchestration,
 // hipGraph capture and the C ABI declared in include/ptts.h.
 #include "ptts_kernels.h"
+#include "ptts_flow.h"
 
 #include <algorithm>
 #include <array>
@@ -8,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -37,20 +39,23 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // launched on and tagged with its call site, its kernel name and its ALGORITHMIC bytes / flops.
 // Off by default (and always off during graph capture); bench.py switches it on for a few eager steps.
 struct ProfRec { std::string site, kernel; double bytes, flops; hipEvent_t a, b; };
-static bool g_prof_on = false;
-static std::vector<ProfRec> g_prof;
+struct Profiler { bool on = false; std::vector<ProfRec> recs; };
+// Per-call context: every entry point binds its engine's profiler / tuner / zero line in the CALLING thread
+// (bind_engine), so two engines driven from two threads never see each other's state.  One engine is driven by one
+// thread at a time (entry points take the engine mutex; see the threading contract in include/ptts.h).
+static thread_local Profiler *g_prof = nullptr;
 static thread_local const char *g_site = "";
 struct ProfScope {
-  hipStream_t st; bool on; size_t idx;
-  ProfScope(hipStream_t st_, const std::string &kernel, double bytes, double flops) : st(st_), on(g_prof_on), idx(0) {
-    if (!on) return;
+  hipStream_t st; Profiler *pr; size_t idx;
+  ProfScope(hipStream_t st_, const std::string &kernel, double bytes, double flops) : st(st_), pr(g_prof && g_prof->on ? g_prof : nullptr), idx(0) {
+    if (!pr) return;
     ProfRec r{g_site, kernel, bytes, flops, nullptr, nullptr};
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { pr = nullptr; return; }
     (void)hipEventRecord(r.a, st);
-    idx = g_prof.size();
-    g_prof.push_back(r);
+    idx = pr->recs.size();
+    pr->recs.push_back(r);
   }
-  ~ProfScope() { if (on) (void)hipEventRecord(g_prof[idx].b, st); }
+  ~ProfScope() { if (pr) (void)hipEventRecord(pr->recs[idx].b, st); }
 };
 #define SITE(x) g_site = (x)
 
@@ -103,8 +108,13 @@ struct ptts_engine {
   float *zeros = nullptr;
   int64_t lm_bytes = 0, mimi_bytes = 0;
   struct Tuner *tuner = nullptr;
+  Profiler prof;
+  int opt_flow_cluster = 1;
+  int opt_k_rotate = 1;
+  std::recursive_mutex mu;  // entry points that enqueue work or touch tuner / profiler / LSD tables hold it
   int quant_flags = 0;
 };
+#define ENGINE_LOCK(e) std::lock_guard<std::recursive_mutex> lock_((e)->mu)
 
 struct Scratch {
   float *x = nullptr, *h = nullptr, *ao = nullptr, *ff = nullptr, *q = nullptr, *part = nullptr, *rope = nullptr;
@@ -121,6 +131,11 @@ struct ptts_lm_state {
   // flow head scratch (FM) + io
   float *xlat, *c, *ce, *mod, *latfm, *fx, *fh, *f1;
   float *fstat = nullptr;  // per-tile row statistics of fx (GemmArgs::stat_out / stat_in)
+  // single-launch flow MLP (flow_cluster_kernel): exchange slots, flags, error word; sized for `flow_steps` LSD steps
+  float *fexch = nullptr;
+  unsigned long long *fflags = nullptr;
+  int *ferr = nullptr;
+  int flow_steps = 0, flow_rt = 1, flow_ng = 1;
   float *lat, *lat_prev;  // plain [B][ldim]
   float *eos_logit;
   uint8_t *is_eos;
@@ -169,8 +184,17 @@ struct ptts_graph {
 // allocation helpers
 // Zero-filled device allocation.  The fill is queued on `st` (the engine stream, which is
 // non-blocking and therefore NOT ordered against the null stream a plain hipMemset would use).
-static hipStream_t g_alloc_stream = nullptr;
+// The zero fill is queued on the stream of the innermost AllocScope of the CALLING thread (thread-local: a
+// concurrent call on another engine / thread can no longer redirect it).
+static thread_local hipStream_t t_alloc_stream = nullptr;
+struct AllocScope {
+  hipStream_t prev;
+  explicit AllocScope(hipStream_t st) : prev(t_alloc_stream) { t_alloc_stream = st; }
+  ~AllocScope() { t_alloc_stream = prev; }
+};
 static int dalloc(ptts_engine *e, void **p, size_t bytes) {
+  hipStream_t st = t_alloc_stream ? t_alloc_stream : (e ? e->stream : nullptr);
+  if (!st) return fail(-1, "internal: allocation outside an AllocScope");
   if (bytes == 0) bytes = 256;
   *p = nullptr;
   const hipError_t err = hipMalloc(p, bytes);
@@ -179,7 +203,7 @@ static int dalloc(ptts_engine *e, void **p, size_t bytes) {
     *p = nullptr;
     return fail(-2, "hipMalloc of " + std::to_string(bytes) + " bytes: " + hipGetErrorString(err));
   }
-  HIPCHK(hipMemsetAsync(*p, 0, bytes, g_alloc_stream));
+  HIPCHK(hipMemsetAsync(*p, 0, bytes, st));
   if (e) e->allocs.push_back(*p);
   return 0;
 }
@@ -187,6 +211,7 @@ template <typename T>
 static int dallocT(ptts_engine *e, T **p, size_t n) {
   return dalloc(e, (void **)p, n * sizeof(T));
 }
+
 
 static const ptts_tensor *find_tensor(ptts_engine *e, const std::string &name, int64_t numel, int *err) {
   auto it = e->tmap.find(name);
@@ -323,7 +348,7 @@ static int make_freq(ptts_engine *e, float **out, float max_period) {
   const float coef = (float)(-std::log((double)max_period) * 2.0 / 64.0);
   for (int i = 0; i < 32; ++i) h[i] = std::exp((float)i * coef);
   CHK(dallocT(e, out, 32));
-  HIPCHK(hipStreamSynchronize(g_alloc_stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy(*out, h, sizeof(h), hipMemcpyHostToDevice));
   return 0;
 }
@@ -460,7 +485,8 @@ static void launch_by_cfg(hipStream_t st, const GemmArgs &a_in, int pre, int cfg
 // batch on scratch states with `active` set: every GEMM shape met for the first time is timed with every valid
 // configuration (caches flushed before each timed launch, as in the real step where ~1 GB streams between two
 // uses of a weight) and the fastest is remembered.  Shapes never tuned fall back to pick_cfg.
-typedef std::array<int, 12> TuneKey;
+typedef std::array<int, 13> TuneKey;
+static constexpr int kTuneVersion = 2;  // bump when the key or the configuration list changes (cache files carry it)
 struct Tuner {
   std::map<TuneKey, int> table;
   bool active = false;
@@ -471,9 +497,10 @@ struct Tuner {
 };
 static thread_local Tuner *g_tuner = nullptr;
 static thread_local const float *g_zeros = nullptr;  // both set by the entry points from the engine
+static thread_local int g_krot = 1;
 
 static TuneKey tune_key(const GemmArgs &a, int pre) {
-  return TuneKey{a.NT, a.KF, a.CF, a.ntaps, a.MT, a.epi, pre, a.act, a.xstride, a.halo_mode, a.Yraw ? 1 : 0, a.R ? 1 : 0};
+  return TuneKey{a.NT, a.KF, a.CF, a.ntaps, a.MT, a.epi, pre, a.act, a.xstride, a.halo_mode, a.Yraw ? 1 : 0, a.R ? 1 : 0, a.Wq ? 1 : 0};
 }
 
 // Evicts L2 and the Infinity Cache by READING a large buffer (a write flush would leave dirty lines whose
@@ -495,6 +522,8 @@ static int tune_one(hipStream_t st, const GemmArgs &a, int pre, Tuner &t) {
       for (const char *p = v; *p;) { m |= 1u << (atoi(p) & 31); while (*p && *p != ',') ++p; if (*p) ++p; }
     return m;
   }();
+  static const bool verbose = getenv("PTTS_TUNE_VERBOSE") != nullptr;  // log every configuration's time
+  std::string all;
   for (int cfg = 0; cfg < kNumCfg; ++cfg) {
     if (!cfg_valid(cfg, a, pre) || ((excl >> cfg) & 1)) continue;
     float ms_min = 1e30f;
@@ -510,18 +539,21 @@ static int tune_one(hipStream_t st, const GemmArgs &a, int pre, Tuner &t) {
     }
     if (cfg == heur) heur_ms = ms_min;
     if (ms_min < best_ms) { best_ms = ms_min; best = cfg; }
+    if (verbose) { char b[64]; snprintf(b, sizeof b, " %d:%.1f", cfg, ms_min * 1e3); all += b; }
   }
   if (best_ms > 1e29f) return heur;
   char line[256];
   snprintf(line, sizeof line, "%s NT=%d KF=%d taps=%d MT=%d epi=%d pre=%d: %s %.1f us (heuristic %s %.1f us)\n", g_site, a.NT,
            a.KF, a.ntaps, a.MT, a.epi, pre, kCfgName[best], best_ms * 1e3, kCfgName[heur], heur_ms * 1e3);
   t.log += line;
+  if (verbose) t.log += "   all (cfg:us)" + all + "\n";
   return best;
 }
 
 static void launch_gemm(hipStream_t st, const GemmArgs &a_in, int pre) {
   GemmArgs a = a_in;
   a.zeros = g_zeros;
+  a.krot = g_krot;
   // algorithmic traffic: weights once + input rows once (x taps re-read from cache, not counted) + output
   const double K = (double)a.KF * 16, N = (double)a.NT * 16, M = (double)a.M;
   double bytes = 4.0 * (N * K + M * (double)a.CF * 16 + M * N);
@@ -574,6 +606,8 @@ static void launch_gemm(hipStream_t st, const GemmArgs &a_in, int pre) {
 static void bind_engine(ptts_engine *e) {
   g_zeros = e->zeros;
   g_tuner = e->tuner;
+  g_prof = &e->prof;
+  g_krot = e->opt_k_rotate;
 }
 
 static GemmArgs mk_gemm(const Lin &L, const float *X, int XF, int MT, int M) {
@@ -722,6 +756,8 @@ extern "C" int ptts_create_ex(const ptts_config *cfg, const ptts_tensor *tensors
   e->device = device;
   e->tuner = new Tuner();
   e->quant_flags = quant_flags;
+  if (const char *v = getenv("PTTS_FLOW_CLUSTER")) e->opt_flow_cluster = atoi(v) != 0;
+  if (const char *v = getenv("PTTS_K_ROTATE")) e->opt_k_rotate = atoi(v) != 0;
   const int rc = build_engine(e, tensors, n);
   if (rc < 0) {  // missing / ill-shaped tensor, HIP error: release what was built so far
     const std::string msg = g_err;
@@ -734,7 +770,7 @@ extern "C" int ptts_create_ex(const ptts_config *cfg, const ptts_tensor *tensors
 
 static int build_engine(ptts_engine *e, const ptts_tensor *tensors, int32_t n) {
   HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-  g_alloc_stream = e->stream;
+  AllocScope alloc_scope(e->stream);
   HIPCHK(hipEventCreate(&e->ev0));
   HIPCHK(hipEventCreate(&e->ev1));
   for (int i = 0; i < n; ++i) e->tmap[tensors[i].name] = &tensors[i];
@@ -858,6 +894,8 @@ extern "C" void ptts_destroy(ptts_engine *e) {
   if (e->ev1) hipEventDestroy(e->ev1);
   if (e->stream) hipStreamDestroy(e->stream);
   if (g_tuner == e->tuner) g_tuner = nullptr;
+  if (g_prof == &e->prof) g_prof = nullptr;
+  for (auto &r : e->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   delete e->tuner;
   delete e;
 }
@@ -871,7 +909,7 @@ static int prepare_lsd(ptts_engine *e, int steps) {
   if (steps < 1 || steps > 64) return fail(-1, "lsd_decode_steps out of range");
   const int FD = e->cfg.flow_dim;
   float *tab;
-  g_alloc_stream = e->stream;
+  AllocScope alloc_scope(e->stream);
   CHK(dallocT(e, &tab, (size_t)steps * FD));
   hipStream_t st = e->stream;
   float *efm = e->te_scratch, *h = efm + 16 * 1024, *h0 = h + 16 * 1024, *h1 = h0 + 16 * 1024;
@@ -918,9 +956,11 @@ static void free_scratch(Scratch *s) {
 }
 
 static int build_lm_state(ptts_engine *e, ptts_lm_state *s);
+static int ensure_flow(ptts_engine *e, ptts_lm_state *s, int steps, hipStream_t st);
 
 extern "C" int ptts_lm_state_create(ptts_engine *e, int32_t B, int32_t t_cap, ptts_lm_state **out) {
   if (!e || !out || B < 1 || t_cap < 1) return fail(-1, "bad argument");
+  ENGINE_LOCK(e);
   HIPCHK(hipSetDevice(e->device));
   ptts_lm_state *s = new ptts_lm_state();
   s->e = e;
@@ -940,7 +980,7 @@ extern "C" int ptts_lm_state_create(ptts_engine *e, int32_t B, int32_t t_cap, pt
 static int build_lm_state(ptts_engine *e, ptts_lm_state *s) {
   const ptts_config &c = e->cfg;
   const int B = s->B;
-  g_alloc_stream = e->stream;
+  AllocScope alloc_scope(e->stream);
   CHK(dallocT(nullptr, &s->kv, (size_t)c.num_layers * 2 * s->kv_plane()));
   CHK(dallocT(nullptr, &s->offset, B));
   s->h_off.assign(B, 0);
@@ -951,7 +991,7 @@ static int build_lm_state(ptts_engine *e, ptts_lm_state *s) {
   CHK(dallocT(nullptr, &s->latfm, rt * (c.ldim / 16)));
   CHK(dallocT(nullptr, &s->c, rt * (c.d_model / 16)));
   CHK(dallocT(nullptr, &s->ce, rt * (FD / 16)));
-  CHK(dallocT(nullptr, &s->mod, rt * e->adaln.NT));
+  CHK(dallocT(nullptr, &s->ferr, 1));
   CHK(dallocT(nullptr, &s->fx, rt * (FD / 16)));
   CHK(dallocT(nullptr, &s->fh, rt * (FD / 16)));
   CHK(dallocT(nullptr, &s->f1, rt * (FD / 16)));
@@ -966,6 +1006,7 @@ static int build_lm_state(ptts_engine *e, ptts_lm_state *s) {
   set_int_kernel<<<cdiv(B, 256), 256, 0, e->stream>>>(s->active, B, 1);
   fill_kernel<<<cdiv(B * c.ldim, 256), 256, 0, e->stream>>>(s->lat_prev, (long)B * c.ldim, NAN);
   HIPCHK(hipStreamSynchronize(e->stream));
+  CHK(ensure_flow(e, s, 1, e->stream));  // AdaLN modulation buffer + flow-cluster exchange slots for lsd_decode_steps = 1
   return 0;
 }
 
@@ -978,6 +1019,7 @@ extern "C" void ptts_lm_state_destroy(ptts_lm_state *s) {
   if (s->pre.x) free_scratch(&s->pre);
   hipFree(s->xlat); hipFree(s->latfm); hipFree(s->c); hipFree(s->ce); hipFree(s->mod); hipFree(s->fx);
   hipFree(s->fh); hipFree(s->f1); hipFree(s->lat); hipFree(s->lat_prev); hipFree(s->eos_logit); hipFree(s->is_eos); hipFree(s->rng_ctr); hipFree(s->active); hipFree(s->fstat);
+  hipFree(s->fexch); hipFree(s->fflags); hipFree(s->ferr);
   delete s;
 }
 
@@ -1032,6 +1074,14 @@ extern "C" int ptts_lm_state_copy(ptts_lm_state *dst, const ptts_lm_state *src, 
     long per_row = (long)c.num_heads * dst->cap * 64;
     long total = (long)c.num_layers * 2 * dst->B * (per_row / 4);
     kv_copy_kernel<<<cdiv(total, 256), 256, 0, st>>>(dst->kv, src->kv, per_row, dst->B, src->B, c.num_layers * 2);
+  } else if (src->B == 1) {
+    // different capacities, one source sequence (a cached voice state cloned into a generation state): one row-copy
+    // kernel per destination row instead of L x 2 x H memcpys
+    if (T)
+      for (int b = 0; b < dst->B; ++b) {
+        const long total = (long)c.num_layers * 2 * c.num_heads * T * 16;
+        kv_copy_row_kernel<<<cdiv(total, 256), 256, 0, st>>>(dst->kv, src->kv, c.num_layers * 2, c.num_heads, T, src->cap, dst->cap, dst->B, b);
+      }
   } else {
     // different capacities: go plane by plane through the reference layout-free row copy
     for (int pl = 0; pl < c.num_layers * 2; ++pl)
@@ -1111,20 +1161,23 @@ extern "C" int ptts_lm_set_noise(ptts_lm_state *s, float temp, uint64_t seed) {
 }
 
 extern "C" int ptts_profile_start(ptts_engine *e) {
-  (void)e;
-  for (auto &r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-  g_prof.clear();
-  g_prof_on = true;
+  if (!e) return fail(-1, "null engine");
+  ENGINE_LOCK(e);
+  for (auto &r : e->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  e->prof.recs.clear();
+  e->prof.on = true;
   return 0;
 }
 
 // Stops profiling and writes one line per (site, kernel): "site kernel count total_ms bytes flops\n"
 extern "C" int64_t ptts_profile_stop(ptts_engine *e, char *h_out, int64_t capacity) {
-  g_prof_on = false;
+  if (!e) return fail(-1, "null engine");
+  ENGINE_LOCK(e);
+  e->prof.on = false;
   if (hipDeviceSynchronize() != hipSuccess) return fail(-2, "sync failed");
   std::map<std::pair<std::string, std::string>, std::array<double, 4>> agg;
   std::vector<std::pair<std::string, std::string>> order;
-  for (auto &r : g_prof) {
+  for (auto &r : e->prof.recs) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, r.a, r.b);
     auto key = std::make_pair(r.site, r.kernel);
@@ -1133,7 +1186,7 @@ extern "C" int64_t ptts_profile_stop(ptts_engine *e, char *h_out, int64_t capaci
     v[0] += 1; v[1] += ms; v[2] += r.bytes; v[3] += r.flops;
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
-  g_prof.clear();
+  e->prof.recs.clear();
   std::string out;
   char line[512];
   for (auto &k : order) {
@@ -1141,10 +1194,84 @@ extern "C" int64_t ptts_profile_stop(ptts_engine *e, char *h_out, int64_t capaci
     snprintf(line, sizeof line, "%s %s %.0f %.6f %.0f %.0f\n", k.first.empty() ? "-" : k.first.c_str(), k.second.c_str(), v[0], v[1], v[2], v[3]);
     out += line;
   }
-  (void)e;
   if ((int64_t)out.size() + 1 > capacity) return fail(-1, "profile buffer too small");
   memcpy(h_out, out.c_str(), out.size() + 1);
   return (int64_t)out.size();
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Single-launch flow MLP (ptts_flow.h).  Geometry per state: RT row tiles per cluster, NG clusters of FDF workgroups.
+static bool flow_cluster_ok(const ptts_engine *e, const ptts_lm_state *s) {
+  const ptts_config &c = e->cfg;
+  const int FDF = c.flow_dim / 16, LF = c.ldim / 16;
+  if (!e->opt_flow_cluster || c.flow_depth > FLOW_MAX_DEPTH || FDF > 64 || LF > FDF) return false;
+  const int kpw = cdiv(std::max(FDF, LF), FLOW_WORKERS);
+  if (kpw != 1 && kpw != 2 && kpw != 4) return false;  // flow_dim <= 512
+  if (!e->input_proj.bias || !e->fin.bias) return false;
+  for (auto &r : e->res) if (!r.l0.bias || !r.l2.bias) return false;
+  // every workgroup of the launch must be resident at once (they wait for each other): stay far below the chip's
+  // capacity of 256 CUs x >= 2 such workgroups
+  return (long)s->flow_ng * FDF <= 512;
+}
+// (re)allocates the per-state buffers whose size depends on the number of LSD steps; never called during capture
+static int ensure_flow(ptts_engine *e, ptts_lm_state *s, int steps, hipStream_t st) {
+  if (steps <= s->flow_steps) return 0;
+  const ptts_config &c = e->cfg;
+  const int FDF = c.flow_dim / 16;
+  s->flow_rt = 1;  // one cluster per 16 rows: rows are independent, the clusters' weight re-reads stay in L2
+  s->flow_ng = cdiv(s->MT, s->flow_rt);
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  AllocScope alloc_scope(st);
+  hipFree(s->mod); hipFree(s->fexch); hipFree(s->fflags);
+  s->mod = nullptr; s->fexch = nullptr; s->fflags = nullptr;
+  const size_t rt = (size_t)s->MT * 256;
+  const int nph = steps * (2 * c.flow_depth + 2);
+  CHK(dallocT(nullptr, &s->mod, (size_t)steps * rt * e->adaln.NT));
+  CHK(dallocT(nullptr, &s->fexch, (size_t)s->flow_ng * nph * s->flow_rt * FDF * 256));
+  CHK(dallocT(nullptr, &s->fflags, (size_t)s->flow_ng * nph * FDF));
+  HIPCHK(hipStreamSynchronize(st));
+  s->flow_steps = steps;
+  return 0;
+}
+
+template <int RT>
+static void launch_flow_rt(hipStream_t st, const FlowArgs &fa, int kpw) {
+  const dim3 grid(fa.NG * fa.FDF), block(FLOW_THREADS);
+  switch (kpw) {
+    case 1: flow_cluster_kernel<RT, 1><<<grid, block, 0, st>>>(fa); break;
+    case 2: flow_cluster_kernel<RT, 2><<<grid, block, 0, st>>>(fa); break;
+    default: flow_cluster_kernel<RT, 4><<<grid, block, 0, st>>>(fa); break;
+  }
+}
+
+static void launch_flow_cluster(hipStream_t st, ptts_engine *e, ptts_lm_state *s, int lsd_steps, float *d_latent_out) {
+  const ptts_config &c = e->cfg;
+  const int FDF = c.flow_dim / 16, LF = c.ldim / 16;
+  FlowArgs fa;
+  memset(&fa, 0, sizeof fa);
+  fa.MT = s->MT; fa.M = s->B; fa.NG = s->flow_ng; fa.FDF = FDF; fa.LF = LF; fa.AF = e->adaln.NT;
+  fa.depth = c.flow_depth; fa.steps = lsd_steps; fa.ldim = c.ldim;
+  fa.w_in = e->input_proj.w; fa.b_in = e->input_proj.bias;
+  for (int r = 0; r < c.flow_depth; ++r) {
+    fa.w_l0[r] = e->res[r].l0.w; fa.b_l0[r] = e->res[r].l0.bias;
+    fa.w_l2[r] = e->res[r].l2.w; fa.b_l2[r] = e->res[r].l2.bias;
+    fa.ln_w[r] = e->res[r].ln_w; fa.ln_b[r] = e->res[r].ln_b;
+  }
+  fa.w_fin = e->fin.w; fa.b_fin = e->fin.bias;
+  fa.mod = s->mod; fa.mod_step = (long)s->MT * 256 * e->adaln.NT;
+  fa.latfm = s->latfm;
+  fa.lat = s->lat; fa.lat_out1 = s->lat_prev; fa.lat_out2 = d_latent_out;
+  fa.inv_steps = 1.0f / (float)lsd_steps;
+  fa.exch = s->fexch; fa.flags = s->fflags; fa.ctr = s->rng_ctr; fa.err = s->ferr;
+  // weights of the chain once per cluster-set (L2 / Infinity Cache absorb the clusters' re-reads) + modulations + io
+  const double wbytes = 4.0 * 256 * ((double)FDF * LF + 2.0 * c.flow_depth * FDF * FDF + (double)LF * FDF);
+  const double flops = 2.0 * s->B * 256.0 * ((double)FDF * LF + 2.0 * c.flow_depth * FDF * FDF + (double)LF * FDF) * lsd_steps;
+  ProfScope ps(st, "flow_cluster@" + std::to_string((long)fa.NG * FDF * FLOW_THREADS),
+               lsd_steps * (wbytes + 4.0 * s->B * 16.0 * e->adaln.NT), flops);
+  const int kpw = cdiv(std::max(FDF, LF), FLOW_WORKERS);
+  launch_flow_rt<1>(st, fa, kpw);
 }
 
 static void lm_layers(hipStream_t st, ptts_engine *e, ptts_lm_state *s, Scratch &sc, int M, int Tq, bool rope_done = false) {
@@ -1172,6 +1299,7 @@ static void lm_layers(hipStream_t st, ptts_engine *e, ptts_lm_state *s, Scratch 
 }
 
 extern "C" int ptts_lm_prefill(ptts_engine *e, ptts_lm_state *s, const float *d_emb, int32_t T, void *stream) {
+  ENGINE_LOCK(e);
   if (T < 1) return 0;
   HIPCHK(hipSetDevice(e->device));
   const ptts_config &c = e->cfg;
@@ -1182,7 +1310,7 @@ extern "C" int ptts_lm_prefill(ptts_engine *e, ptts_lm_state *s, const float *d_
   if (!s->pre.x || s->pre.MT < cdiv(M, 16) || s->pre.QB != cdiv(T, 16)) {
     HIPCHK(hipStreamSynchronize(st));
     if (s->pre.x) free_scratch(&s->pre);
-    g_alloc_stream = st;
+    AllocScope alloc_scope(st);
     CHK(alloc_scratch(e, &s->pre, s->B, T, c.d_model, c.num_heads, c.ff_dim, s->cap));
   }
   Scratch &sc = s->pre;
@@ -1226,6 +1354,18 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
   a.eos_logit2 = d_eos_logit; a.is_eos2 = d_is_eos;  // caller's buffers are written by the epilogue itself
   launch_gemm(st, a, PRE_LNFOLD);
   const int AF = e->adaln.NT;
+  if (flow_cluster_ok(e, s) && lsd_steps <= s->flow_steps) {
+    // the AdaLN modulations of every LSD step (they depend on the step's (s, t) only through t_emb), then the whole
+    // chain + Euler loop in ONE launch
+    for (int i = 0; i < lsd_steps; ++i) {
+      SITE("flow.adaln");
+      a = mk_gemm(e->adaln, s->ce, FDF, MT, B);
+      a.prevec = tcomb + (size_t)i * FD; a.Y = s->mod + (size_t)i * MT * 256 * AF; a.YF = AF;
+      launch_gemm(st, a, PRE_ADDSILU);
+    }
+    SITE("flow.cluster");
+    launch_flow_cluster(st, e, s, lsd_steps, d_latent_out);
+  } else
   for (int i = 0; i < lsd_steps; ++i) {
     // all AdaLN modulations of the step in one GEMM on silu(t_emb + cond)  (mlp.py:107,127,210)
     SITE("flow.adaln");
@@ -1276,8 +1416,10 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
 extern "C" int ptts_lm_decode_step(ptts_engine *e, ptts_lm_state *s, const float *d_latent_in, const float *d_noise,
                                    int32_t lsd_steps, float eos_threshold, float *d_latent_out, float *d_eos_logit,
                                    uint8_t *d_is_eos, void *stream) {
+  ENGINE_LOCK(e);
   HIPCHK(hipSetDevice(e->device));
   CHK(prepare_lsd(e, lsd_steps));
+  CHK(ensure_flow(e, s, lsd_steps, S(e, stream)));
   for (int b = 0; b < s->B; ++b)
     if (s->h_off[b] + 1 > s->cap) return fail(-5, "decode: KV cache capacity exceeded");
   CHK(lm_step_enqueue(S(e, stream), e, s, d_latent_in, d_noise, lsd_steps, eos_threshold, d_latent_out, d_eos_logit, d_is_eos));
@@ -1292,6 +1434,7 @@ static int build_mimi_state(ptts_engine *e, ptts_mimi_state *s);
 
 extern "C" int ptts_mimi_state_create(ptts_engine *e, int32_t B, ptts_mimi_state **out) {
   if (!e || !out || B < 1) return fail(-1, "bad argument");
+  ENGINE_LOCK(e);
   HIPCHK(hipSetDevice(e->device));
   ptts_mimi_state *s = new ptts_mimi_state();
   s->e = e;
@@ -1309,7 +1452,7 @@ extern "C" int ptts_mimi_state_create(ptts_engine *e, int32_t B, ptts_mimi_state
 static int build_mimi_state(ptts_engine *e, ptts_mimi_state *s) {
   const ptts_config &c = e->cfg;
   const int B = s->B;
-  g_alloc_stream = e->stream;
+  AllocScope alloc_scope(e->stream);
   s->MTb = cdiv(B, 16);
   s->MT16 = B;  // one 16-row tile per sequence
   const int C = c.m_dim, CF = C / 16;
@@ -1495,6 +1638,7 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
 }
 
 extern "C" int ptts_mimi_decode(ptts_engine *e, ptts_mimi_state *s, const float *d_latent, float *d_pcm, void *stream) {
+  ENGINE_LOCK(e);
   HIPCHK(hipSetDevice(e->device));
   if (!d_latent) return fail(-1, "null latent");
   CHK(mimi_enqueue(S(e, stream), e, s, d_latent, d_pcm));
@@ -1507,6 +1651,7 @@ extern "C" int ptts_mimi_decode(ptts_engine *e, ptts_mimi_state *s, const float 
 // Tile autotuning for one batch size (see Tuner).  Runs on scratch states; the caller's states are untouched.
 extern "C" int ptts_tune(ptts_engine *e, int32_t B, void *stream) {
   if (!e || B < 1) return fail(-1, "bad argument");
+  ENGINE_LOCK(e);
   HIPCHK(hipSetDevice(e->device));
   hipStream_t st = S(e, stream);
   Tuner &t = *e->tuner;
@@ -1522,13 +1667,13 @@ extern "C" int ptts_tune(ptts_engine *e, int32_t B, void *stream) {
   if (rc == 0 && (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess)) rc = fail(-2, "hipEventCreate");
   if (rc == 0) {
     HIPCHK(hipStreamSynchronize(e->stream));  // state zero-fills
-    const bool prof = g_prof_on;
-    g_prof_on = false;
+    const bool prof = e->prof.on;
+    e->prof.on = false;
     t.active = true;
     rc = ptts_lm_decode_step(e, ls, nullptr, nullptr, 1, 1e30f, nullptr, nullptr, nullptr, st);
     if (rc == 0) rc = ptts_mimi_decode(e, ms, ls->lat, nullptr, st);
     t.active = false;
-    g_prof_on = prof;
+    e->prof.on = prof;
     if (hipStreamSynchronize(st) != hipSuccess && rc == 0) rc = fail(-2, "tune: stream error");
   }
   if (t.e0) hipEventDestroy(t.e0);
@@ -1541,11 +1686,13 @@ extern "C" int ptts_tune(ptts_engine *e, int32_t B, void *stream) {
   return rc;
 }
 
+extern "C" int ptts_tune_version(void) { return kTuneVersion; }
 extern "C" const char *ptts_tune_log(ptts_engine *e) { return e ? e->tuner->log.c_str() : ""; }
 
-// The tuned table as text, one line per shape: the 12 key integers (tune_key) then the configuration index.
+// The tuned table as text, one line per shape: the 13 key integers (tune_key) then the configuration index.
 extern "C" int64_t ptts_tune_export(ptts_engine *e, char *h_out, int64_t capacity) {
   if (!e) return fail(-1, "null engine");
+  ENGINE_LOCK(e);
   std::string out;
   char line[256];
   for (auto &kv : e->tuner->table) {
@@ -1561,12 +1708,13 @@ extern "C" int64_t ptts_tune_export(ptts_engine *e, char *h_out, int64_t capacit
 
 extern "C" int ptts_tune_import(ptts_engine *e, const char *text) {
   if (!e || !text) return fail(-1, "null argument");
+  ENGINE_LOCK(e);
   const char *p = text;
   int n_ok = 0;
   while (*p) {
     TuneKey k;
     int cfg = -1, consumed = 0, ok = 1;
-    for (int i = 0; i < 12 && ok; ++i) {
+    for (int i = 0; i < 13 && ok; ++i) {
       if (sscanf(p, "%d%n", &k[i], &consumed) != 1) ok = 0;
       else p += consumed;
     }
@@ -1593,13 +1741,14 @@ extern "C" void ptts_tune_clear(ptts_engine *e) {
 // zero / replicate left padding and an input stride.
 extern "C" int ptts_encode_voice(ptts_engine *e, const float *d_audio, int64_t n_samples, float *d_latent_out,
                                  float *d_cond_out, int32_t *h_frames, void *stream) {
+  ENGINE_LOCK(e);
   if (!e->has_encoder) return fail(-3, "the checkpoint passed to ptts_create has no Mimi encoder tensors");
   if (n_samples < 1) return fail(-1, "empty audio");
   HIPCHK(hipSetDevice(e->device));
   const ptts_config &c = e->cfg;
   hipStream_t st = S(e, stream);
   bind_engine(e);
-  g_alloc_stream = st;
+  AllocScope alloc_scope(st);
   const int hop = c.ratios[0] * c.ratios[1] * c.ratios[2];
   const long fs = (long)hop * c.upsample_stride;  // 1920
   const long R0 = (n_samples + fs - 1) / fs * fs;  // pad_for_conv1d(x, frame_size, frame_size)
@@ -1721,8 +1870,10 @@ static int capture(ptts_engine *e, ptts_graph *g, F &&body) {
 extern "C" int ptts_graph_capture_lm_step(ptts_engine *e, ptts_lm_state *s, const float *d_noise, int32_t lsd_steps,
                                           float eos_threshold, float *d_latent_out, float *d_eos_logit,
                                           uint8_t *d_is_eos, ptts_graph **out) {
+  ENGINE_LOCK(e);
   HIPCHK(hipSetDevice(e->device));
   CHK(prepare_lsd(e, lsd_steps));
+  CHK(ensure_flow(e, s, lsd_steps, e->stream));
   ptts_graph *g = new ptts_graph();
   g->lm = s;
   CHK(capture(e, g, [&](hipStream_t st) {
@@ -1734,6 +1885,7 @@ extern "C" int ptts_graph_capture_lm_step(ptts_engine *e, ptts_lm_state *s, cons
 
 extern "C" int ptts_graph_capture_mimi(ptts_engine *e, ptts_mimi_state *s, const float *d_latent, float *d_pcm,
                                        ptts_graph **out) {
+  ENGINE_LOCK(e);
   HIPCHK(hipSetDevice(e->device));
   ptts_graph *g = new ptts_graph();
   g->mimi = s;
@@ -1749,8 +1901,10 @@ extern "C" int ptts_graph_capture_pipelined(ptts_engine *e, ptts_lm_state *s, pt
                                             int32_t lsd_steps, float eos_threshold, float *d_latent_out,
                                             float *d_eos_logit, uint8_t *d_is_eos, const float *d_mimi_latent_in,
                                             float *d_pcm, ptts_graph **out) {
+  ENGINE_LOCK(e);
   HIPCHK(hipSetDevice(e->device));
   CHK(prepare_lsd(e, lsd_steps));
+  CHK(ensure_flow(e, s, lsd_steps, e->stream));
   ptts_graph *g = new ptts_graph();
   g->lm = s;
   g->mimi = m;
@@ -1780,6 +1934,7 @@ extern "C" int ptts_graph_capture_pipelined(ptts_engine *e, ptts_lm_state *s, pt
 
 extern "C" int ptts_graph_launch(ptts_graph *g, void *stream) {
   ptts_engine *e = g->lm ? g->lm->e : g->mimi->e;
+  ENGINE_LOCK(e);
   if (g->lm) {
     for (int b = 0; b < g->lm->B; ++b)
       if (g->lm->h_off[b] + 1 > g->lm->cap) return fail(-5, "decode: KV cache capacity exceeded");
@@ -1799,6 +1954,23 @@ extern "C" void ptts_graph_destroy(ptts_graph *g) {
 }
 
 // ------------------------------------------------------------------------------------------------
+extern "C" int ptts_set_option(ptts_engine *e, const char *key, int32_t value) {
+  if (!e || !key) return fail(-1, "null argument");
+  ENGINE_LOCK(e);
+  const std::string k(key);
+  if (k == "flow_cluster") e->opt_flow_cluster = value != 0;
+  else if (k == "k_rotate") e->opt_k_rotate = value != 0;
+  else return fail(-1, "unknown option " + k);
+  return 0;
+}
+extern "C" int ptts_lm_state_error(ptts_lm_state *s, void *stream) {
+  if (!s) return fail(-1, "null state");
+  int h = 0;
+  hipStream_t st = S(s->e, stream);
+  HIPCHK(hipMemcpyAsync(&h, s->ferr, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return h != 0;
+}
 extern "C" int ptts_sync(ptts_engine *e, void *stream) {
   HIPCHK(hipStreamSynchronize(S(e, stream)));
   return 0;

@@ -62,6 +62,8 @@ struct GemmArgs {
   const uint8_t *Wq;
   const float *wscale;
   int swz;  // XCD-aware workgroup -> tile mapping (tile_of_block)
+  int krot;  // Linear layers, K-split tiles: workgroup bx starts its K loop at chunk bx % nchunks, so the column blocks that
+             // re-read the same activation rows do not request the same L2 lines at the same time
   // Row statistics hand-over (flow MLP): a producer (EPI_STORE / EPI_GATE) also writes, per output tile, each row's
   // (sum, sum of squares) over the tile's 16 columns to stat_out[((mt * NT + nt) * 16 + row) * 2]; the PRE_LNMOD
   // consumer then adds stat_nt partials per row instead of re-reading the whole row (fixed order, deterministic).
@@ -437,6 +439,7 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
   constexpr int U = (Q8 && U0 < 4) ? 4 : U0;  // int8 weights arrive four k-fragments per load
   auto load_chunk = [&](auto uc, int kf, f32x4 (*w)[TN], f32x4 (*x)[TM]) {
     constexpr int UU = decltype(uc)::value;
+    if (a.ntaps == 1) cf = kf;  // a Linear's fragments are addressed by k alone (chunks may come in rotated order)
 #pragma unroll
     for (int u = 0; u < UU; ++u) {
 #pragma unroll
@@ -528,32 +531,32 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
   };
   const std::integral_constant<int, U> cU{};
   const std::integral_constant<int, 1> c1{};
-  int kf = k0;
   const int nfull = (k1 - k0) / U;
+  // chunk c of this wave covers k-fragments kfc(c) .. kfc(c) + U - 1; rotated by the column block for Linear layers
+  const int rot = (a.krot && a.ntaps == 1 && nfull > 1) ? (int)(bx % nfull) : 0;
+  auto kfc = [&](int c) { int i = c + rot; if (i >= nfull) i -= nfull; return k0 + i * U; };
   if (nfull > 0) {
     // Two register sets: chunk c+1 is in flight while chunk c feeds the MFMAs.  The steady-state loop issues
     // its prefetches unconditionally (the tail is peeled), so the wait counts stay exact.  A decode wave that
     // owns several chunks of a long K (FFN2: 4) no longer pays one full HBM round trip per chunk.
     f32x4 wA[U][TN], xA[U][TM], wB[U][TN], xB[U][TM];
-    load_chunk(cU, kf, wA, xA);
+    load_chunk(cU, kfc(0), wA, xA);
     int c = 0;
     for (; c + 2 < nfull; c += 2) {
-      load_chunk(cU, kf + U, wB, xB);
-      compute_chunk(cU, kf, wA, xA);
-      load_chunk(cU, kf + 2 * U, wA, xA);
-      compute_chunk(cU, kf + U, wB, xB);
-      kf += 2 * U;
+      load_chunk(cU, kfc(c + 1), wB, xB);
+      compute_chunk(cU, kfc(c), wA, xA);
+      load_chunk(cU, kfc(c + 2), wA, xA);
+      compute_chunk(cU, kfc(c + 1), wB, xB);
     }
     if (c + 1 < nfull) {
-      load_chunk(cU, kf + U, wB, xB);
-      compute_chunk(cU, kf, wA, xA);
-      compute_chunk(cU, kf + U, wB, xB);
-      kf += 2 * U;
+      load_chunk(cU, kfc(c + 1), wB, xB);
+      compute_chunk(cU, kfc(c), wA, xA);
+      compute_chunk(cU, kfc(c + 1), wB, xB);
     } else {
-      compute_chunk(cU, kf, wA, xA);
-      kf += U;
+      compute_chunk(cU, kfc(c), wA, xA);
     }
   }
+  int kf = k0 + nfull * U;
   if constexpr (Q8) {
     const std::integral_constant<int, 4> c4{};  // host guarantees (k1 - k0) % 4 == 0
     for (; kf < k1; kf += 4) {

@@ -70,6 +70,12 @@ class LMState:
         """device-side N(0, temp) noise for steps called with noise=None (perf runs)"""
         _lib.check(self.engine.lib.ptts_lm_set_noise(self.handle, float(temp), int(seed)))
 
+    def error(self) -> bool:
+        """True after a cooperative kernel of this state gave up waiting for a peer workgroup"""
+        r = self.engine.lib.ptts_lm_state_error(self.handle, self.engine._sp)
+        _lib.check(min(int(r), 0))
+        return bool(r)
+
     def offsets(self) -> np.ndarray:
         out = (C.c_int32 * self.batch)()
         _lib.check(self.engine.lib.ptts_lm_state_offsets(self.handle, out, self.engine._sp))
@@ -213,6 +219,10 @@ class Engine:
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
     # ---- utilities
+    def set_option(self, key: str, value: int):
+        """engine options of include/ptts.h (`flow_cluster`, ...); applies to later steps / captures"""
+        _lib.check(self.lib.ptts_set_option(self.handle, key.encode(), int(value)))
+
     def sync(self):
         _lib.check(self.lib.ptts_sync(self.handle, self._sp))
 
@@ -230,29 +240,44 @@ class Engine:
 
     def tune(self, batch: int, force: bool = False) -> str:
         """Measure the tile configuration of every GEMM on the step path for this batch size (once per
-        engine and batch; `PTTS_NO_TUNE=1` keeps the static heuristic).  Returns the tuner's log."""
+        engine and batch; `PTTS_NO_TUNE=1` keeps the static heuristic).  Returns the tuner's log.
+
+        `PTTS_TUNE_CACHE=<file>`: tile choices measured by an earlier process are imported first (a deployment,
+        or a profiling run whose counters would perturb the timings, reuses them).  The tuner then still runs:
+        it only measures GEMM shapes ABSENT from the table (another model, batch or weight format), so a cache
+        never silently leaves shapes on the heuristic.  Newly measured shapes are appended to
+        `PTTS_TUNE_CACHE_OUT` (default: the cache file itself).  Files carry the table-format version."""
         if os.environ.get("PTTS_NO_TUNE") == "1" or (batch in self._tuned and not force):
             return ""
-        # PTTS_TUNE_CACHE=<file>: tile choices are read from / appended to a text file, so that a deployment (or
-        # a profiling run, whose counters would perturb the timings) reuses the choices of an earlier process
+        ver = int(self.lib.ptts_tune_version())
+        head = f"# ptts-tune-version {ver}\n"
         cache = os.environ.get("PTTS_TUNE_CACHE")
-        tag = f"# batch {int(batch)}\n"
+        out = os.environ.get("PTTS_TUNE_CACHE_OUT", cache)
         if cache and os.path.exists(cache) and not force:
             text = open(cache).read()
-            if tag in text:
+            if text.startswith(head):
                 self.lib.ptts_tune_import(self.handle, text.encode())
-                self._tuned.add(batch)
-                return ""
+        before = self._tune_table()
         self._pre()
         _lib.check(self.lib.ptts_tune(self.handle, int(batch), self._sp))
         self._tuned.add(batch)
-        if cache:
-            buf = C.create_string_buffer(1 << 20)
-            n = self.lib.ptts_tune_export(self.handle, buf, len(buf))
-            _lib.check(int(n))
-            with open(cache, "a") as f:
-                f.write(tag + buf.value.decode())
+        after = self._tune_table()
+        new = [ln for ln in after if ln not in before]
+        if out and new:
+            t = self.cfg.flow_lm.transformer
+            fresh = not os.path.exists(out) or not open(out).read().startswith(head)
+            with open(out, "w" if fresh else "a") as f:
+                if fresh:
+                    f.write(head)
+                f.write(f"# batch {int(batch)} d_model {t.d_model} layers {t.num_layers} "
+                        f"quant {'+'.join(sorted(self.quantize_groups)) or 'none'}\n" + "\n".join(new) + "\n")
         return (self.lib.ptts_tune_log(self.handle) or b"").decode()
+
+    def _tune_table(self) -> list:
+        buf = C.create_string_buffer(1 << 20)
+        n = self.lib.ptts_tune_export(self.handle, buf, len(buf))
+        _lib.check(int(n))
+        return [ln for ln in buf.value.decode().splitlines() if ln.strip()]
 
     def profile_start(self):
         _lib.check(self.lib.ptts_profile_start(self.handle))

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import logging
 import math
+import threading
 import time
 from pathlib import Path
 
@@ -88,6 +89,8 @@ class TTSModel:
         self.origin = origin
         self.has_voice_cloning = engine.has_voice_encoder
         self._ctx_cache: dict = {}
+        self._voice_cache: dict = {}  # id(model_state) -> (signature, LMState, tensors): device-resident voice states
+        self._voice_lock = threading.Lock()  # the cache is shared with ContinuousBatcher's scheduler thread
         self.pad_with_spaces_for_short_inputs = config.pad_with_spaces_for_short_inputs
         self.model_recommended_frames_after_eos = config.model_recommended_frames_after_eos
         self.remove_semicolons = config.remove_semicolons
@@ -288,6 +291,29 @@ class TTSModel:
             if n_emit[b] is None or frame < n_emit[b]:
                 chunks[b].append(pcm[b].clone())
 
+    def _voice_lm_state(self, model_state: dict, t_voice: int):
+        """Device-resident engine-layout copy of a voice state dict, built on first use and reused while the dict's
+        tensors are unchanged (same storage, same in-place version, same offset); at most 8 voices stay resident."""
+        with self._voice_lock:
+            return self._voice_lm_state_locked(model_state, t_voice)
+
+    def _voice_lm_state_locked(self, model_state: dict, t_voice: int):
+        eng = self.engine
+        sig = tuple((model_state[_layer_key(i)]["cache"].data_ptr(), model_state[_layer_key(i)]["cache"]._version)
+                    for i in range(eng.L)) + (t_voice,)
+        hit = self._voice_cache.get(id(model_state))
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        if hit is not None:
+            hit[1].close()
+        while len(self._voice_cache) >= 8:
+            self._voice_cache.pop(next(iter(self._voice_cache)))[1].close()
+        vst = eng.new_lm_state(1, max(t_voice, 1))
+        _import_lm_state(eng, vst, model_state, t_voice)
+        # the entry keeps the source tensors alive, so a recycled id() / data_ptr() can never alias a cached voice
+        self._voice_cache[id(model_state)] = (sig, vst, [model_state[_layer_key(i)]["cache"] for i in range(eng.L)])
+        return vst
+
     def _draw_noise(self, out: torch.Tensor):
         """Same draws as the reference CPU path (flow_lm.py:131-137): torch's global CPU generator."""
         std = self.temp ** 0.5
@@ -315,13 +341,14 @@ class TTSModel:
             ms = eng.new_mimi_state(1)
             noise_dev = torch.zeros(1, eng.ldim, device=self.device) if use_noise else None
             pipe = StepPipeline(eng, st, ms, noise_dev, self.lsd_decode_steps, float(self.eos_threshold), mode="hostsync")
-            ctx = dict(st=st, ms=ms, noise_dev=noise_dev, pipe=pipe)
+            ctx = dict(st=st, ms=ms, noise_dev=noise_dev, pipe=pipe, noise_host=torch.zeros(1, eng.ldim).pin_memory())
         st, ms, noise_dev, pipe = ctx["st"], ctx["ms"], ctx["noise_dev"], ctx["pipe"]
-        st.reset()
+        noise_host = ctx["noise_host"]
         pipe.restart()
-        _import_lm_state(eng, st, model_state, t_voice)       # replaces deepcopy + _expand_kv_cache
+        # per-chunk clone of the voice state (replaces deepcopy + _expand_kv_cache, tts_model.py:637-638,390-421): the
+        # voice's KV lives on the device in the engine's layout, one row-copy kernel clones it, nothing synchronises
+        st.copy_from(self._voice_lm_state(model_state, t_voice))
         eng.lm_prefill(st, eng.embed_text(tokens))            # text prefill (tts_model.py:722-725)
-        noise_host = torch.zeros(1, eng.ldim).pin_memory()
         if use_noise:
             # the reference's text prefill runs the whole forward, including one (discarded) noise draw
             # (tts_model.py:722-725 -> flow_lm.py:131-137): consume it to stay on the same generator stream

@@ -353,6 +353,17 @@ def test_tuned_table_export_import_roundtrip(tmp_path, monkeypatch):
     eng.lib.ptts_tune_export(eng.handle, buf, len(buf))
     assert buf.value.decode() == table1
     assert eng.lib.ptts_tune_import(eng.handle, b"garbage line\n1 2 3\n") == 0
+    # a batch with other GEMM shapes: the cached shapes are reused, the missing ones are measured and appended
+    # (a cache hit must never leave another batch / model on the static heuristic)
+    size1 = cache.stat().st_size
+    log2 = eng.tune(40)
+    assert log2 and "seanet.convtr1" in log2 and cache.stat().st_size > size1
+    assert cache.read_text().startswith(f"# ptts-tune-version {eng.lib.ptts_tune_version()}")
+    # a file of another table version is ignored, not imported
+    cache.write_text("# ptts-tune-version 0\n" + "\n".join(table1.splitlines()))
+    eng.lib.ptts_tune_clear(eng.handle)
+    eng._tuned.clear()
+    assert eng.tune(5) != ""
 
 
 def test_failed_creation_releases_and_reports():

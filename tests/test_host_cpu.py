@@ -110,3 +110,25 @@ def test_pmc_tool_labels_match_the_profiler_labels():
     assert n("attn_kernel(AttnArgs)") == "attn"
     assert n("attn_combine_kernel(AttnArgs)") == "attn_combine"
     assert n("step_tail_kernel(int*, int, int, int*, int const*)") == "step_tail"
+
+
+def test_bench_presets_and_rank_spawning():
+    """bench.py: `--preset config4` is BASELINE.json configs[3] (24-layer model, 32 utterances per GPU); `--gpus N`
+    without a launcher spawns N ranks itself and exits non-zero when a rank fails (here: no GPU in this container)."""
+    import subprocess
+    import sys
+
+    import bench
+
+    a = bench.parse(["--preset", "config4", "--gpus", "8"])
+    assert (a.config, a.batch, a.gpus, a.quantize) == ("24l", 32, 8, False)
+    a = bench.parse([])
+    assert (a.config, a.batch, a.gpus, a.steps) == ("en100m", 64, 1, 125)
+    assert bench.parse(["--preset", "int8"]).quantize and bench.parse(["--batch", "4", "--preset", "b1"]).batch == 4
+    import torch
+
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, bench.__file__, "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0
+        assert "rank 0 exited" in r.stderr and "rank 1 exited" in r.stderr
