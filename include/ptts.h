@@ -175,13 +175,18 @@ int ptts_tune_import(ptts_engine *e, const char *text);
 /* Engine options (experiments / A-B tests; defaults come from the environment variable in brackets):
  *   "flow_cluster"  [PTTS_FLOW_CLUSTER, 1]  1 = the flow MLP of a decode step runs as ONE cooperative launch
  *                                           (ptts_flow.h), 0 = one GEMM launch per layer
- *   "k_rotate"      [PTTS_K_ROTATE, 1]      1 = K-split GEMM workgroups start their K loop at a column-block dependent
+ *   "k_rotate"      [PTTS_K_ROTATE, 0]      1 = K-split GEMM workgroups start their K loop at a column-block dependent
  *                                           chunk (spreads the re-reads of the shared activation rows over L2 channels)
  * Applies to steps enqueued / graphs captured after the call.  Returns -1 for an unknown key. */
 int ptts_set_option(ptts_engine *e, const char *key, int32_t value);
 /* 1 after a cooperative kernel of this state gave up waiting for a peer workgroup (its outputs are then invalid);
  * synchronises the stream.  Never 1 unless the GPU was oversubscribed beyond the contract above. */
 int ptts_lm_state_error(ptts_lm_state *s, void *stream);
+/* A HIP stream restricted to CUs [cu_lo, cu_hi) of every XCD (hipExtStreamCreateWithCUMask; 32 CUs per XCD on
+ * MI355X): work queued on it - eager launches and graph launches alike - leaves the other CUs to the other streams.
+ * Destroy with ptts_stream_destroy after the work queued on it has finished. */
+int ptts_stream_create_masked(ptts_engine *e, int32_t cu_lo, int32_t cu_hi, void **out_stream);
+int ptts_stream_destroy(void *stream);
 int ptts_sync(ptts_engine *e, void *stream);
 void *ptts_engine_stream(ptts_engine *e);
 /* asynchronous device -> pinned-host copy on `stream` (PCM chunks, EOS flags) */

@@ -80,6 +80,8 @@ PROTOTYPES = {
     "ptts_tune_version": (C.c_int, []),
     "ptts_set_option": (C.c_int, [_P, C.c_char_p, C.c_int32]),
     "ptts_lm_state_error": (C.c_int, [_P, _P]),
+    "ptts_stream_create_masked": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "ptts_stream_destroy": (C.c_int, [_P]),
     "ptts_sync": (C.c_int, [_P, _P]),
     "ptts_engine_stream": (_P, [_P]),
     "ptts_copy_to_host_async": (C.c_int, [_P, _P, _P, C.c_int64, _P]),

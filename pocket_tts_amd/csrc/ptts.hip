@@ -110,7 +110,7 @@ struct ptts_engine {
   struct Tuner *tuner = nullptr;
   Profiler prof;
   int opt_flow_cluster = 1;
-  int opt_k_rotate = 1;
+  int opt_k_rotate = 0;
   std::recursive_mutex mu;  // entry points that enqueue work or touch tuner / profiler / LSD tables hold it
   int quant_flags = 0;
 };
@@ -1202,6 +1202,7 @@ extern "C" int64_t ptts_profile_stop(ptts_engine *e, char *h_out, int64_t capaci
 
 // ------------------------------------------------------------------------------------------------
 // Single-launch flow MLP (ptts_flow.h).  Geometry per state: RT row tiles per cluster, NG clusters of FDF workgroups.
+static constexpr int kFlowMaxCUs = 128;  // half of the 256 CUs: the codec stream (and its CU share) stays alive beside it
 static bool flow_cluster_ok(const ptts_engine *e, const ptts_lm_state *s) {
   const ptts_config &c = e->cfg;
   const int FDF = c.flow_dim / 16, LF = c.ldim / 16;
@@ -1210,9 +1211,9 @@ static bool flow_cluster_ok(const ptts_engine *e, const ptts_lm_state *s) {
   if (kpw != 1 && kpw != 2 && kpw != 4) return false;  // flow_dim <= 512
   if (!e->input_proj.bias || !e->fin.bias) return false;
   for (auto &r : e->res) if (!r.l0.bias || !r.l2.bias) return false;
-  // every workgroup of the launch must be resident at once (they wait for each other): stay far below the chip's
-  // capacity of 256 CUs x >= 2 such workgroups
-  return (long)s->flow_ng * FDF <= 512;
+  // every workgroup of the launch must be resident at once (they wait for each other) and a 9-wave workgroup fills a
+  // CU: the grid is capped at kFlowMaxCUs workgroups (larger batches loop over row groups inside the kernel)
+  return FDF <= kFlowMaxCUs;
 }
 // (re)allocates the per-state buffers whose size depends on the number of LSD steps; never called during capture
 static int ensure_flow(ptts_engine *e, ptts_lm_state *s, int steps, hipStream_t st) {
@@ -1238,7 +1239,7 @@ static int ensure_flow(ptts_engine *e, ptts_lm_state *s, int steps, hipStream_t 
 
 template <int RT>
 static void launch_flow_rt(hipStream_t st, const FlowArgs &fa, int kpw) {
-  const dim3 grid(fa.NG * fa.FDF), block(FLOW_THREADS);
+  const dim3 grid(fa.NCL * fa.FDF), block(FLOW_THREADS);
   switch (kpw) {
     case 1: flow_cluster_kernel<RT, 1><<<grid, block, 0, st>>>(fa); break;
     case 2: flow_cluster_kernel<RT, 2><<<grid, block, 0, st>>>(fa); break;
@@ -1251,7 +1252,7 @@ static void launch_flow_cluster(hipStream_t st, ptts_engine *e, ptts_lm_state *s
   const int FDF = c.flow_dim / 16, LF = c.ldim / 16;
   FlowArgs fa;
   memset(&fa, 0, sizeof fa);
-  fa.MT = s->MT; fa.M = s->B; fa.NG = s->flow_ng; fa.FDF = FDF; fa.LF = LF; fa.AF = e->adaln.NT;
+  fa.MT = s->MT; fa.M = s->B; fa.NG = s->flow_ng; fa.NCL = std::max(1, std::min(s->flow_ng, kFlowMaxCUs / FDF)); fa.FDF = FDF; fa.LF = LF; fa.AF = e->adaln.NT;
   fa.depth = c.flow_depth; fa.steps = lsd_steps; fa.ldim = c.ldim;
   fa.w_in = e->input_proj.w; fa.b_in = e->input_proj.bias;
   for (int r = 0; r < c.flow_depth; ++r) {
@@ -1268,7 +1269,7 @@ static void launch_flow_cluster(hipStream_t st, ptts_engine *e, ptts_lm_state *s
   // weights of the chain once per cluster-set (L2 / Infinity Cache absorb the clusters' re-reads) + modulations + io
   const double wbytes = 4.0 * 256 * ((double)FDF * LF + 2.0 * c.flow_depth * FDF * FDF + (double)LF * FDF);
   const double flops = 2.0 * s->B * 256.0 * ((double)FDF * LF + 2.0 * c.flow_depth * FDF * FDF + (double)LF * FDF) * lsd_steps;
-  ProfScope ps(st, "flow_cluster@" + std::to_string((long)fa.NG * FDF * FLOW_THREADS),
+  ProfScope ps(st, "flow_cluster@" + std::to_string((long)fa.NCL * FDF * FLOW_THREADS),
                lsd_steps * (wbytes + 4.0 * s->B * 16.0 * e->adaln.NT), flops);
   const int kpw = cdiv(std::max(FDF, LF), FLOW_WORKERS);
   launch_flow_rt<1>(st, fa, kpw);
@@ -1970,6 +1971,31 @@ extern "C" int ptts_lm_state_error(ptts_lm_state *s, void *stream) {
   HIPCHK(hipMemcpyAsync(&h, s->ferr, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   return h != 0;
+}
+// A stream whose kernels run on a subset of the CUs (hipExtStreamCreateWithCUMask): CUs [cu_lo, cu_hi) of EVERY XCD.
+// Measured on MI355X / ROCm 7.2 (tools/cu_mask_probe.py): mask bit i addresses CU i / 8 of XCD i % 8, a kernel runs
+// at the speed of its most-masked XCD (workgroups are dealt round-robin over the XCDs), and the mask applies to graph
+// launches on the stream as well.  Lets the codec stream leave a slice of every XCD to the latency-bound FlowLM stream.
+extern "C" int ptts_stream_create_masked(ptts_engine *e, int32_t cu_lo, int32_t cu_hi, void **out) {
+  if (!e || !out) return fail(-1, "bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, e->device));
+  const int ncu = prop.multiProcessorCount, nxcd = 8, per = ncu / nxcd, words = (ncu + 31) / 32;
+  if (cu_lo < 0 || cu_hi > per || cu_lo >= cu_hi) return fail(-1, "CU range must lie inside [0, CUs per XCD)");
+  std::vector<uint32_t> mask(words, 0u);
+  for (int i = 0; i < ncu; ++i) {
+    const int c = i / nxcd;
+    if (c >= cu_lo && c < cu_hi) mask[i >> 5] |= 1u << (i & 31);
+  }
+  hipStream_t st = nullptr;
+  HIPCHK(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()));
+  *out = (void *)st;
+  return 0;
+}
+extern "C" int ptts_stream_destroy(void *stream) {
+  if (stream) HIPCHK(hipStreamDestroy((hipStream_t)stream));
+  return 0;
 }
 extern "C" int ptts_sync(ptts_engine *e, void *stream) {
   HIPCHK(hipStreamSynchronize(S(e, stream)));

@@ -33,7 +33,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 
 struct FlowArgs {
-  int MT, M, NG, FDF, LF, AF, depth, steps, ldim;
+  int MT, M, NG, NCL, FDF, LF, AF, depth, steps, ldim;  // NG row groups of RT tiles, served by NCL resident clusters
   const float *w_in, *b_in;  // input_proj, packed [FDF][LF][64][4]
   const float *w_l0[FLOW_MAX_DEPTH], *b_l0[FLOW_MAX_DEPTH], *w_l2[FLOW_MAX_DEPTH], *b_l2[FLOW_MAX_DEPTH];
   const float *ln_w[FLOW_MAX_DEPTH], *ln_b[FLOW_MAX_DEPTH];
@@ -78,17 +78,22 @@ template <int RT, int KPW>
 __global__ __launch_bounds__(FLOW_THREADS) void flow_cluster_kernel(FlowArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int FDF = a.FDF, LF = a.LF;
-  const int grp = blockIdx.x % a.NG, j = blockIdx.x / a.NG;  // cluster, column tile
-  const int mt0 = grp * RT;
+  const int cl = blockIdx.x % a.NCL, j = blockIdx.x / a.NCL;  // resident cluster, column tile
   const bool coord = wave == FLOW_WORKERS;
   const int PPS = 2 * a.depth + 2, NPH = a.steps * PPS;
   __shared__ f32x4 red[FLOW_WORKERS][RT][64];
   __shared__ float st[FLOW_WORKERS][RT][16][2];
   const u64 ebase = ((u64)(unsigned)(*a.ctr) + 1ull) << 16;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  bool dead = false;  // coordinator only: a poll gave up; finish without waiting (outputs are garbage, *err is set)
+  // a resident cluster serves row groups cl, cl + NCL, ..: at most NCL * FDF workgroups wait for each other, however
+  // large the batch is (a 9-wave workgroup of this kernel fills a CU: residency is one workgroup per CU)
+  for (int grp = cl; grp < a.NG; grp += a.NCL) {
+  const int mt0 = grp * RT;
   float *ex = a.exch + (size_t)grp * NPH * RT * FDF * 256;
   u64 *fl = a.flags + (size_t)grp * NPH * FDF;
   const __amdgpu_buffer_rsrc_t rs = flow_rsrc(ex);
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();  // LDS of the previous group is free
 
   int mtc[RT];  // clamped row tiles (a partially filled last cluster computes duplicates and stores nothing for them)
 #pragma unroll
@@ -149,7 +154,6 @@ __global__ __launch_bounds__(FLOW_THREADS) void flow_cluster_kernel(FlowArgs a) 
   } else {
     load_w(0);
   }
-  bool dead = false;  // coordinator only: a poll gave up; finish without waiting (outputs are garbage, *err is set)
 
   for (int p = 0; p < NPH; ++p) {
     const int i = p / PPS, ph = p - i * PPS;
@@ -293,4 +297,5 @@ __global__ __launch_bounds__(FLOW_THREADS) void flow_cluster_kernel(FlowArgs a) 
 #pragma unroll
     for (int t = 0; t < RT; ++t) e_gate[t] = n_gate[t];
   }
+  }  // row groups
 }

@@ -83,6 +83,11 @@ class LMState:
 
     def import_layer(self, layer: int, cache: torch.Tensor, t: int):
         """cache: f32[2, Bsrc, >=t, H, 64] in the reference layout (reference transformer.py:32-36)."""
+        e = self.engine
+        if cache.dim() != 5 or cache.shape[0] != 2 or cache.shape[1] not in (1, self.batch) or cache.shape[2] < t \
+                or cache.shape[3] != e.H or cache.shape[4] != 64:
+            raise ValueError(f"voice-state cache of layer {layer}: expected [2, 1|{self.batch}, >={t}, {e.H}, 64], "
+                             f"got {tuple(cache.shape)}")
         cache = cache[:, :, :t].to(self.engine.device, torch.float32).contiguous()
         self.engine._pre()
         _lib.check(self.engine.lib.ptts_lm_state_import(self.handle, layer, _ptr(cache), cache.shape[1], t, self.engine._sp))
