@@ -15,7 +15,7 @@ lands in pinned host memory inside the timed region.
 per GPU, rendezvous on 127.0.0.1; under `torch.distributed.run` the ranks it is given are used.  Utterances are
 independent: each rank runs the same work on its own GPU, RCCL carries only the barriers and a few scalars, scaling is
 "weak".  Presets: `config4` = 24-layer model, 32 utterances per GPU (BASELINE.json configs[3], meant for --gpus 8);
-`b1` = batch 1; `int8` = configs[4] first half (int8 LM weights), a separate line, never the headline.
+`b1` = batch 1; `int8` / `bf16codec` / `config5` = configs[4] (int8 LM weights, bf16 codec, both): separate lines, never the headline.
 
 Weights are synthetic (seed 0), data synthetic; fp32 end to end like the reference.  Rank 0 prints ONE JSON line.
 """
@@ -43,6 +43,8 @@ PRESETS = {
     "config4": dict(config="24l", batch=32),
     "b1": dict(batch=1),
     "int8": dict(quantize=True),
+    "bf16codec": dict(codec_bf16=True),
+    "config5": dict(quantize=True, codec_bf16=True),
 }
 
 
@@ -63,6 +65,8 @@ def parse(argv=None):
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--quantize", action="store_true", default=None,
                     help="BASELINE config #5: int8 weights for the FlowLM attention + FFN layers (not the headline)")
+    ap.add_argument("--codec-bf16", action="store_true", default=None,
+                    help="BASELINE config #5, second half: bf16 Mimi decoder, fp32 accumulate (not the headline)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the cpu_baseline leg")
     ap.add_argument("--latency-trials", type=int, default=200)
     args = ap.parse_args(argv)
@@ -72,6 +76,7 @@ def parse(argv=None):
     args.batch = 64 if args.batch is None else args.batch
     args.config = args.config or "en100m"
     args.quantize = bool(args.quantize)
+    args.codec_bf16 = bool(args.codec_bf16)
     return args
 
 
@@ -386,7 +391,8 @@ def main():
 
     cfg = named_config(args.config)
     W = generate_state_dict(cfg, 0)
-    eng = Engine(cfg, W, dev, quantize_groups={"attention", "ffn"} if args.quantize else None)
+    groups = ({"attention", "ffn"} if args.quantize else set()) | ({"codec_bf16"} if args.codec_bf16 else set())
+    eng = Engine(cfg, W, dev, quantize_groups=groups or None)
     job = Job(eng, args.batch, args, seed=rank)
 
     def barrier():
@@ -436,7 +442,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int8 weights (FlowLM attention+ffn), f32 activations/accumulate" if args.quantize else "f32",
+            "dtype": " + ".join(([("int8 weights (FlowLM attention+ffn), f32 activations/accumulate")] if args.quantize else [])
+                                + (["bf16 codec (weights+activations), f32 accumulate"] if args.codec_bf16 else [])) or "f32",
             "data": "synthetic (seeded weights, voice KV, token ids; fixed-length utterances, EOS stop disabled)",
             "config": {
                 "workload": f"{args.config}: batch {args.batch} concurrent utterances/GPU, voice KV {args.voice_len} + "

@@ -67,8 +67,20 @@ int ptts_create(const ptts_config *cfg, const ptts_tensor *tensors, int32_t n_te
  * stay fp32, so the result is closer to the fp32 model than the reference's int8 path.  flags = 0 == ptts_create. */
 #define PTTS_QUANT_ATTENTION 1 /* self_attn.in_proj, self_attn.out_proj */
 #define PTTS_QUANT_FFN 2       /* linear1, linear2 */
+/* Reduced-precision CODEC (BASELINE.json config #5, second half; no reference counterpart, parity unpinned): the Mimi
+ * decoder-transformer GEMMs and the SEANet decoder convolutions run with bf16 weights and bf16 activations, fp32
+ * accumulation (v_mfma_f32_16x16x32_bf16) and fp32 epilogue math; attention, the KV ring and the FlowLM stay fp32, so
+ * EOS decisions / frame counts are those of the fp32 model.  Quality: tests/test_gpu_bf16.py (SNR vs the fp32 path). */
+#define PTTS_CODEC_BF16 4
 int ptts_create_ex(const ptts_config *cfg, const ptts_tensor *tensors, int32_t n_tensors, int32_t device,
                    int32_t quant_flags, ptts_engine **out);
+/* Packed-engine files ("offline packer"): ptts_engine_save writes everything ptts_create[_ex] built on
+ * the device (MFMA-fragment-ordered weights, int8 / bf16 images, LayerNorm-fold vectors) to one file;
+ * ptts_create_from_file rebuilds the engine from it without the checkpoint and without packing or quantising again
+ * (the reference re-quantises at every load: quantization.py:60-88, tts_model.py:312-313).  The file is tied to this
+ * library's ABI version and layout; a mismatch is reported (-3), never loaded. */
+int ptts_engine_save(ptts_engine *e, const char *path);
+int ptts_create_from_file(const char *path, int32_t device, ptts_engine **out);
 void ptts_destroy(ptts_engine *e);
 
 /* ---- FlowLM state: init_states(flow_lm, B, T) (stateful_module.py:7-16, transformer.py:46-57) */

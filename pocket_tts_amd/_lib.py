@@ -44,6 +44,8 @@ PROTOTYPES = {
     "ptts_last_error": (C.c_char_p, []),
     "ptts_create": (C.c_int, [C.POINTER(PttsConfig), C.POINTER(PttsTensor), C.c_int32, C.c_int32, C.POINTER(_P)]),
     "ptts_create_ex": (C.c_int, [C.POINTER(PttsConfig), C.POINTER(PttsTensor), C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "ptts_engine_save": (C.c_int, [_P, C.c_char_p]),
+    "ptts_create_from_file": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(_P)]),
     "ptts_destroy": (None, [_P]),
     "ptts_lm_state_create": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(_P)]),
     "ptts_lm_state_destroy": (None, [_P]),

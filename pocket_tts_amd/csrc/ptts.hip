@@ -2,6 +2,7 @@
 // hipGraph capture and the C ABI declared in include/ptts.h.
 #include "ptts_kernels.h"
 #include "ptts_flow.h"
+#include "ptts_bf16.h"
 
 #include <algorithm>
 #include <array>
@@ -68,6 +69,9 @@ struct Lin {  // one packed weight matrix
   // int8 weight-only variant (PTTS_QUANT_*): wq replaces w; ln_g = the LayerNorm gain applied to x on load
   uint8_t *wq = nullptr;
   float *wscale = nullptr, *ln_g = nullptr;
+  // bf16 twin for the reduced-precision codec path (PTTS_CODEC_BF16): packed [NT][ntaps * C/32][64][8], ln_s from the rounded image
+  __bf16 *wh = nullptr;
+  float *ln_s_h = nullptr;
   size_t bytes() const { return wq ? (size_t)NT * KF * 256 + (size_t)NT * 64 : (size_t)NT * KF * 1024; }
 };
 
@@ -82,6 +86,10 @@ struct ptts_engine {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<void *> allocs;
+  std::map<void *, size_t> alloc_bytes;  // engine-owned allocations and their sizes (packed-engine files)
+  size_t n_build_allocs = 0;             // allocs[0 .. n) were made by build_engine, in a deterministic order
+  const ptts_tensor *blob_dummy = nullptr;  // ptts_create_from_file: every checkpoint lookup resolves to this zero tensor
+  int blob_has_encoder = 0;
   std::map<std::string, const ptts_tensor *> tmap;
   // FlowLM
   float *bos = nullptr, *freq_lm = nullptr;
@@ -100,6 +108,9 @@ struct ptts_engine {
   float *quant_w = nullptr;  // quantizer.output_proj weight [C][ldim], plain (mimi_prologue_kernel)
   std::vector<TrLayer> mm;
   Lin conv0, convtr[3], res_a[3], res_b[3], conv_last;
+  float *conv_last_w = nullptr, *conv_last_b = nullptr;  // plain checkpoint tensors (bf16 path's last conv)
+  bool codec_bf16 = false;
+  int64_t mimi_bytes_h = 0;
   int ring = 0;
   // voice-prompt encode path (SEANet encoder, encoder transformer, downsample, speaker projection)
   bool has_encoder = false;
@@ -204,7 +215,7 @@ static int dalloc(ptts_engine *e, void **p, size_t bytes) {
     return fail(-2, "hipMalloc of " + std::to_string(bytes) + " bytes: " + hipGetErrorString(err));
   }
   HIPCHK(hipMemsetAsync(*p, 0, bytes, st));
-  if (e) e->allocs.push_back(*p);
+  if (e) { e->allocs.push_back(*p); e->alloc_bytes[*p] = bytes; }
   return 0;
 }
 template <typename T>
@@ -214,6 +225,7 @@ static int dallocT(ptts_engine *e, T **p, size_t n) {
 
 
 static const ptts_tensor *find_tensor(ptts_engine *e, const std::string &name, int64_t numel, int *err) {
+  if (e->blob_dummy) return e->blob_dummy;  // loading a packed engine: the packing kernels run on zeros, the real images follow
   auto it = e->tmap.find(name);
   if (it == e->tmap.end()) {
     *err = fail(-3, "missing tensor: " + name);
@@ -318,10 +330,38 @@ static int pack_lin(ptts_engine *e, Lin *L, const std::vector<PackPart> &parts, 
     // the fp32 image is only the quantiser's input
     HIPCHK(hipStreamSynchronize(e->stream));
     e->allocs.erase(std::remove(e->allocs.begin(), e->allocs.end(), (void *)L->w), e->allocs.end());
+    e->alloc_bytes.erase((void *)L->w);
     HIPCHK(hipFree(L->w));
     L->w = nullptr;
   }
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+
+// bf16 twin of a packed matrix for the reduced-precision codec path (single-part matrices only)
+static int pack_lin_h(ptts_engine *e, Lin *L, const std::string &wname, int N, int C, int ntaps, int mode = 0, int cout = 0,
+                      int stride = 0, const std::string &ln_w = "") {
+  if (C % 32) return fail(-4, "bf16 codec path: channel count must be a multiple of 32: " + wname);
+  int err = 0;
+  const ptts_tensor *t = find_tensor(e, wname, -1, &err);
+  if (!t) return err;
+  const float *gam = nullptr;
+  if (!ln_w.empty()) {
+    const ptts_tensor *tg = find_tensor(e, ln_w, C, &err);
+    if (!tg) return err;
+    gam = tg->d_data;
+  }
+  const int KBt = (C / 32) * ntaps;
+  const long total = (long)L->NT * KBt * 512;
+  CHK(dalloc(e, (void **)&L->wh, (size_t)total * 2));
+  pack_weight_h_kernel<<<cdiv(total, 256), 256, 0, e->stream>>>(t->d_data, L->wh, N, C, ntaps, mode, cout, stride, KBt, total, gam);
+  if (gam) {
+    CHK(dallocT(e, &L->ln_s_h, (size_t)L->NT * 16));
+    fold_s_h_kernel<<<N, 64, 0, e->stream>>>(L->wh, L->ln_s_h, N, KBt);
+  }
+  HIPCHK(hipGetLastError());
+  e->mimi_bytes_h += total * 2;
   return 0;
 }
 
@@ -688,7 +728,7 @@ static void run_tr_layer(hipStream_t st, const TrLayer &T, const TrCtx &c) {
   launch_gemm(st, a, PRE_LNFOLD);
   AttnArgs at;
   at.Q = c.q; at.Kc = c.Kc; at.Vc = c.Vc; at.offset = c.offset; at.H = c.H; at.Tq = c.Tq; at.QB = c.QB;
-  at.cap = c.cap; at.ring = c.ring; at.ctx = c.ctx; at.splits = c.splits; at.part = c.part; at.Y = c.ao; at.YF = DF;
+  at.cap = c.cap; at.ring = c.ring; at.ctx = c.ctx; at.splits = c.splits; at.part = c.part; at.Y = c.ao; at.YF = DF; at.h16 = 0;
   const int BH = (c.M / c.Tq) * c.H;
   SITE(s3.c_str());
   {
@@ -748,7 +788,7 @@ extern "C" int ptts_create(const ptts_config *cfg, const ptts_tensor *tensors, i
 extern "C" int ptts_create_ex(const ptts_config *cfg, const ptts_tensor *tensors, int32_t n, int32_t device,
                               int32_t quant_flags, ptts_engine **out) {
   if (!cfg || !tensors || !out) return fail(-1, "null argument");
-  if (quant_flags & ~(PTTS_QUANT_ATTENTION | PTTS_QUANT_FFN)) return fail(-1, "unknown quantisation group");
+  if (quant_flags & ~(PTTS_QUANT_ATTENTION | PTTS_QUANT_FFN | PTTS_CODEC_BF16)) return fail(-1, "unknown quantisation group");
   CHK(seanet_check(*cfg));
   HIPCHK(hipSetDevice(device));
   ptts_engine *e = new ptts_engine();
@@ -851,7 +891,35 @@ static int build_engine(ptts_engine *e, const ptts_tensor *tensors, int32_t n) {
     CHK(pack_lin(e, &e->conv_last, {{m + ".conv.weight", m + ".conv.bias", 1}}, nf, c.last_kernel_size));
   }
   CHK(dallocT(e, &e->zeros, 64));
-  if (e->tmap.count("mimi.encoder.model.0.conv.weight") && e->tmap.count("flow_lm.speaker_proj_weight")) {
+  if (e->quant_flags & PTTS_CODEC_BF16) {
+    // bf16 images of every codec GEMM (reference modules: mimi_transformer.py:12-54, seanet.py:141-180, conv.py:93-163)
+    for (int l = 0; l < c.m_layers; ++l) {
+      const std::string q = "mimi.decoder_transformer.transformer.layers." + std::to_string(l);
+      TrLayer &T = e->mm[l];
+      CHK(pack_lin_h(e, &T.qkv, q + ".self_attn.in_proj.weight", 3 * C, C, 1, 0, 0, 0, q + ".norm1.weight"));
+      CHK(pack_lin_h(e, &T.out, q + ".self_attn.out_proj.weight", C, C, 1));
+      CHK(pack_lin_h(e, &T.ff1, q + ".linear1.weight", c.m_ff, C, 1, 0, 0, 0, q + ".norm2.weight"));
+      CHK(pack_lin_h(e, &T.ff2, q + ".linear2.weight", C, c.m_ff, 1));
+    }
+    CHK(pack_lin_h(e, &e->conv0, "mimi.decoder.model.0.conv.weight", 8 * nf, C, c.kernel_size));
+    int m2 = 8, i2 = 1;
+    for (int i = 0; i < 3; ++i) {
+      const int cin = m2 * nf, cout = cin / 2, sr = c.ratios[i], hid = cout / c.compress;
+      CHK(pack_lin_h(e, &e->convtr[i], "mimi.decoder.model." + std::to_string(i2 + 1) + ".convtr.weight", sr * cout, cin, 2, 1, cout, sr));
+      const std::string r = "mimi.decoder.model." + std::to_string(i2 + 2);
+      CHK(pack_lin_h(e, &e->res_a[i], r + ".block.1.conv.weight", hid, cout, c.res_kernel_size));
+      CHK(pack_lin_h(e, &e->res_b[i], r + ".block.3.conv.weight", cout, hid, 1));
+      i2 += 3;
+      m2 /= 2;
+    }
+    const std::string lc = "mimi.decoder.model." + std::to_string(i2 + 1);
+    CHK(copy_vec(e, lc + ".conv.weight", (int64_t)nf * c.last_kernel_size, &e->conv_last_w));
+    CHK(copy_vec(e, lc + ".conv.bias", 1, &e->conv_last_b, 4));
+    e->codec_bf16 = true;
+    e->mimi_bytes_h += (int64_t)C * c.ldim * 4;
+  }
+  if (e->blob_dummy ? e->blob_has_encoder != 0
+                    : (e->tmap.count("mimi.encoder.model.0.conv.weight") && e->tmap.count("flow_lm.speaker_proj_weight"))) {
     // reference mimi.py:96-119, seanet.py:63-104, resample.py:7-29, tts_model.py:379-388
     int em = 1, eidx = 1;
     CHK(pack_lin(e, &e->enc_conv0, {{"mimi.encoder.model.0.conv.weight", "mimi.encoder.model.0.conv.bias", nf}}, 16,
@@ -882,6 +950,104 @@ static int build_engine(ptts_engine *e, const ptts_tensor *tensors, int32_t n) {
   for (int i = 0; i < 3; ++i) e->mimi_bytes += e->convtr[i].bytes() + e->res_a[i].bytes() + e->res_b[i].bytes();
   HIPCHK(hipStreamSynchronize(e->stream));
   e->tmap.clear();
+  e->n_build_allocs = e->allocs.size();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Packed-engine files (SURVEY 8(f).4 "offline packer"): everything build_engine leaves on the device - weights in MFMA
+// fragment order, int8 / bf16 images, LayerNorm-fold vectors, small tables - as one file, so a deployment neither
+// needs the fp32 checkpoint on the device nor re-packs / re-quantises at every start (reference load-time hook:
+// quantization.py:60-88).  Layout: header, sizes, then the allocations in build order, each padded to 256 bytes.
+struct PackHeader {
+  char magic[8];
+  int32_t abi, tune_version;
+  ptts_config cfg;
+  int32_t quant_flags, has_encoder;
+  int64_t n_allocs;
+};
+static const char kPackMagic[8] = {'P', 'T', 'T', 'S', 'P', 'K', '1', 0};
+
+extern "C" int ptts_engine_save(ptts_engine *e, const char *path) {
+  if (!e || !path) return fail(-1, "null argument");
+  ENGINE_LOCK(e);
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipDeviceSynchronize());
+  FILE *f = fopen(path, "wb");
+  if (!f) return fail(-1, std::string("cannot open ") + path);
+  PackHeader h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, kPackMagic, 8);
+  h.abi = PTTS_ABI_VERSION; h.tune_version = kTuneVersion; h.cfg = e->cfg; h.quant_flags = e->quant_flags;
+  h.has_encoder = e->has_encoder ? 1 : 0; h.n_allocs = (int64_t)e->n_build_allocs;
+  bool ok = fwrite(&h, sizeof h, 1, f) == 1;
+  std::vector<int64_t> sizes;
+  for (size_t i = 0; i < e->n_build_allocs; ++i) sizes.push_back((int64_t)e->alloc_bytes[e->allocs[i]]);
+  ok = ok && fwrite(sizes.data(), 8, sizes.size(), f) == sizes.size();
+  std::vector<char> buf;
+  for (size_t i = 0; i < e->n_build_allocs && ok; ++i) {
+    const size_t n = (size_t)sizes[i], padded = (n + 255) / 256 * 256;
+    buf.assign(padded, 0);
+    if (hipMemcpy(buf.data(), e->allocs[i], n, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+    ok = fwrite(buf.data(), 1, padded, f) == padded;
+  }
+  ok = (fclose(f) == 0) && ok;
+  return ok ? 0 : fail(-2, std::string("writing ") + path + " failed");
+}
+
+extern "C" int ptts_create_from_file(const char *path, int32_t device, ptts_engine **out) {
+  if (!path || !out) return fail(-1, "null argument");
+  FILE *f = fopen(path, "rb");
+  if (!f) return fail(-1, std::string("cannot open ") + path);
+  PackHeader h;
+  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, kPackMagic, 8) != 0 || h.abi != PTTS_ABI_VERSION || h.n_allocs < 1 ||
+      h.n_allocs > 100000) {
+    fclose(f);
+    return fail(-3, std::string(path) + " is not a packed engine of this library version");
+  }
+  std::vector<int64_t> sizes((size_t)h.n_allocs);
+  if (fread(sizes.data(), 8, sizes.size(), f) != sizes.size()) { fclose(f); return fail(-3, "truncated packed engine (sizes)"); }
+  if (seanet_check(h.cfg) < 0) { fclose(f); return -4; }
+  if (hipSetDevice(device) != hipSuccess) { fclose(f); return fail(-2, "hipSetDevice"); }
+  // the largest checkpoint tensor any packing kernel reads (a zero stand-in: the images it produces are overwritten)
+  const ptts_config &c = h.cfg;
+  const int64_t big = std::max<int64_t>({(int64_t)c.ff_dim * c.d_model, (int64_t)3 * c.d_model * c.d_model, (int64_t)c.m_ff * c.m_dim,
+                                         (int64_t)c.m_dim * c.m_dim * c.kernel_size, (int64_t)16 * c.n_filters * c.n_filters * 16,
+                                         (int64_t)3 * c.flow_dim * c.flow_dim, (int64_t)c.m_dim * c.ldim * 2 * c.upsample_stride}) * 2;
+  float *zeros = nullptr;
+  if (hipMalloc((void **)&zeros, (size_t)big * 4) != hipSuccess || hipMemset(zeros, 0, (size_t)big * 4) != hipSuccess) {
+    (void)hipGetLastError();
+    fclose(f);
+    return fail(-2, "out of device memory");
+  }
+  ptts_tensor dummy{"<packed>", zeros, -1};
+  ptts_engine *e = new ptts_engine();
+  e->cfg = h.cfg;
+  e->device = device;
+  e->tuner = new Tuner();
+  e->quant_flags = h.quant_flags;
+  if (const char *v = getenv("PTTS_FLOW_CLUSTER")) e->opt_flow_cluster = atoi(v) != 0;
+  e->blob_dummy = &dummy;
+  e->blob_has_encoder = h.has_encoder;
+  int rc = build_engine(e, nullptr, 0);
+  e->blob_dummy = nullptr;
+  std::string msg = g_err;
+  if (rc == 0 && (int64_t)e->n_build_allocs != h.n_allocs) { rc = -3; msg = "packed engine does not match this build's layout"; }
+  std::vector<char> buf;
+  for (size_t i = 0; rc == 0 && i < e->n_build_allocs; ++i) {
+    const size_t n = (size_t)sizes[i], padded = (n + 255) / 256 * 256;
+    if (e->alloc_bytes[e->allocs[i]] != n) { rc = -3; msg = "packed engine does not match this build's layout (allocation size)"; break; }
+    buf.resize(padded);
+    if (fread(buf.data(), 1, padded, f) != padded) { rc = -3; msg = "truncated packed engine"; break; }
+    if (hipMemcpy(e->allocs[i], buf.data(), n, hipMemcpyHostToDevice) != hipSuccess) { rc = -2; msg = "hipMemcpy"; break; }
+  }
+  fclose(f);
+  (void)hipFree(zeros);
+  if (rc < 0) {
+    ptts_destroy(e);
+    return fail(rc, msg);
+  }
+  *out = e;
   return 0;
 }
 
@@ -1531,15 +1697,16 @@ extern "C" int ptts_mimi_state_reset_row(ptts_mimi_state *s, int32_t row, void *
   if (!s || row < 0 || row >= s->B) return fail(-1, "reset_row: row out of range");
   hipStream_t st = S(s->e, stream);
   const int CF = s->e->cfg.m_dim / 16;
+  const int div = s->e->codec_bf16 ? 2 : 1;  // bf16 activations: a sequence's block is half as many floats, at half the offset
   set_int_kernel<<<1, 64, 0, st>>>(s->offset + row, 1, 0);
   for (int par = 0; par < 2; ++par) {
     zero_row_fm_kernel<<<cdiv(CF * 16, 256), 256, 0, st>>>(s->zq + par * s->zq_stride, CF, row);
     // 16-row tiles: a sequence owns whole tiles, i.e. one contiguous block of every FM buffer
-    const size_t tr = (size_t)s->tr_stride / s->B, a0 = (size_t)s->a0_stride / s->B;
+    const size_t tr = (size_t)s->tr_stride / s->B / div, a0 = (size_t)s->a0_stride / s->B / div;
     HIPCHK(hipMemsetAsync(s->tr_out + par * s->tr_stride + row * tr, 0, tr * 4, st));
     HIPCHK(hipMemsetAsync(s->a0 + par * s->a0_stride + row * a0, 0, a0 * 4, st));
     for (int i = 0; i < 3; ++i) {
-      const size_t cs = (size_t)s->c_stride[i] / s->B, ss = (size_t)s->s_stride[i] / s->B;
+      const size_t cs = (size_t)s->c_stride[i] / s->B / div, ss = (size_t)s->s_stride[i] / s->B / div;
       HIPCHK(hipMemsetAsync(s->cbuf[i] + par * s->c_stride[i] + row * cs, 0, cs * 4, st));
       HIPCHK(hipMemsetAsync(s->sbuf[i] + par * s->s_stride[i] + row * ss, 0, ss * 4, st));
     }
@@ -1556,7 +1723,160 @@ extern "C" int ptts_mimi_set_pcm_i16(ptts_mimi_state *s, int16_t *d_pcm_i16) {
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Reduced-precision codec (ptts_bf16.h): tile choice is static (the kernels are bandwidth / launch bound: bf16 MFMA
+// runs at 16x the fp32 rate) - the largest workgroup tile that still yields >= ~2 workgroups per CU.
+template <int TN, int TM, int WN, int WM>
+static void launch_h_cfg(hipStream_t st, const GemmArgs &a, int pre) {
+  const dim3 grid(cdiv(a.NT, TN * WN), cdiv(a.MT, TM * WM)), block(64 * WN * WM);
+  if (pre == PRE_LNFOLD) gemm_h_kernel<TN, TM, WN, WM, PRE_LNFOLD><<<grid, block, 0, st>>>(a);
+  else gemm_h_kernel<TN, TM, WN, WM, PRE_NONE><<<grid, block, 0, st>>>(a);
+}
+static void launch_gemm_h(hipStream_t st, const GemmArgs &a_in, int pre, const Lin &L) {
+  GemmArgs a = a_in;
+  a.W = (const float *)L.wh;
+  a.CF = L.C / 32;
+  a.KF = a.CF * L.ntaps;
+  if (pre == PRE_LNFOLD) a.ln_s = L.ln_s_h;
+  a.swz = 0;
+  const double K = (double)a.KF * 32, N = (double)a.NT * 16, M = (double)a.M;
+  double bytes = 2.0 * (N * K + M * (double)a.CF * 32 + M * N * (a.Yraw ? 2 : 1)) + (a.epi == EPI_RES ? 2.0 * M * N : 0.0);
+  if (a.epi == EPI_QKV) bytes += 2.0 * M * N;  // q / k / v leave as fp32
+  static const int tiles[4][4] = {{2, 4, 2, 2}, {2, 2, 2, 2}, {1, 2, 2, 2}, {1, 1, 2, 2}};
+  int pick = 3;
+  for (int i = 0; i < 4; ++i) {
+    const int *t = tiles[i];
+    if (t[0] * t[2] > 2 * a.NT && i < 3) continue;  // mostly padding
+    if ((long)cdiv(a.NT, t[0] * t[2]) * cdiv(a.MT, t[1] * t[3]) >= 512 || i == 3) { pick = i; break; }
+  }
+  static const char *const names[4] = {"gemm_h<2,4,2,2>", "gemm_h<2,2,2,2>", "gemm_h<1,2,2,2>", "gemm_h<1,1,2,2>"};
+  const int *t = tiles[pick];
+  ProfScope ps(st, std::string(names[pick]) + (pre == PRE_LNFOLD ? "+ln" : "") + "@" +
+                       std::to_string((long)cdiv(a.NT, t[0] * t[2]) * cdiv(a.MT, t[1] * t[3]) * 256), bytes, 2.0 * M * N * K);
+  switch (pick) {
+    case 0: launch_h_cfg<2, 4, 2, 2>(st, a, pre); break;
+    case 1: launch_h_cfg<2, 2, 2, 2>(st, a, pre); break;
+    case 2: launch_h_cfg<1, 2, 2, 2>(st, a, pre); break;
+    default: launch_h_cfg<1, 1, 2, 2>(st, a, pre); break;
+  }
+}
+
+// the codec frame with bf16 activations: same dataflow, buffers and carries as mimi_enqueue (the fp32 buffers are
+// reused, half filled); block counts are per 32 channels
+static int mimi_enqueue_h(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, const float *d_latent, float *d_pcm) {
+  const ptts_config &c = e->cfg;
+  bind_engine(e);
+  const int B = s->B, C = c.m_dim, CB = C / 32, st16 = c.upsample_stride;
+  SITE("mimi.prologue");
+  {
+    ProfScope ps(st, "mimi_prologue", 4.0 * (B * c.ldim + (double)C * c.ldim) + B * C * (8.0 + 2.0 * st16), 2.0 * B * C * (c.ldim + 2.0 * st16));
+    const int nb_main = cdiv((long)B * (C / 4) * st16, 256);
+    mimi_prologue_kernel<<<nb_main + cdiv(B * st16 * 32, 256), 256, 0, st>>>(
+        d_latent, e->emb_std, e->emb_mean, e->quant_w, e->up_w, s->zq, s->zq_stride, s->frame, s->u0, B, c.ldim, C, st16,
+        nb_main, RopeArgs{s->offset, e->freq_mimi, s->rope, B * st16, st16}, 1);
+  }
+  const int M16 = B * st16, MT16 = s->MT16;
+  GemmArgs a;
+  for (int l = 0; l < c.m_layers; ++l) {
+    const TrLayer &T = e->mm[l];
+    float *x_in = l == 0 ? s->u0 : s->u;
+    const bool last = l == c.m_layers - 1;
+    SITE("mimi.qkv");
+    a = mk_gemm(T.qkv, x_in, CB, MT16, M16);
+    a.epi = EPI_QKV;
+    a.Q = s->q; a.Kc = s->K(l); a.Vc = s->V(l); a.offset = s->offset; a.rope = s->rope;
+    a.H = c.m_heads; a.Tq = st16; a.QB = 1; a.cap = e->ring; a.ring = e->ring;
+    launch_gemm_h(st, a, PRE_LNFOLD, T.qkv);
+    AttnArgs at;
+    at.Q = s->q; at.Kc = s->K(l); at.Vc = s->V(l); at.offset = s->offset; at.H = c.m_heads; at.Tq = st16; at.QB = 1;
+    at.cap = e->ring; at.ring = e->ring; at.ctx = c.m_context; at.splits = s->splits; at.part = s->part; at.Y = s->ao; at.YF = CB;
+    at.h16 = 1;
+    const int BH = B * c.m_heads;
+    SITE("mimi.attn");
+    {
+      const double keys = (double)B * std::min(e->ring, (s->h_frame + 1) * st16);
+      ProfScope ps(st, "attn@" + std::to_string((long)BH * s->splits * 64), keys * c.m_heads * 64 * 4 * 2 + 6.0 * M16 * C, 4.0 * keys * c.m_heads * 64 * 16);
+      attn_kernel<<<dim3(BH, 1, s->splits), 64, 0, st>>>(at);
+    }
+    if (s->splits > 1) {
+      ProfScope ps(st, "attn_combine", (double)BH * s->splits * 16 * ATT_PSTRIDE * 4, 0);
+      attn_combine_kernel<<<dim3(BH, 1), 256, 0, st>>>(at);
+    }
+    SITE("mimi.out");
+    a = mk_gemm(T.out, s->ao, CB, MT16, M16);
+    a.epi = EPI_RES; a.R = x_in; a.RF = CB; a.Y = s->u; a.YF = CB; a.ls = T.ls1;
+    launch_gemm_h(st, a, PRE_NONE, T.out);
+    SITE("mimi.ff1");
+    a = mk_gemm(T.ff1, s->u, CB, MT16, M16);
+    a.epi = EPI_STORE; a.act = ACT_GELU; a.Y = s->ff; a.YF = c.m_ff / 32;
+    launch_gemm_h(st, a, PRE_LNFOLD, T.ff1);
+    SITE("mimi.ff2");
+    a = mk_gemm(T.ff2, s->ff, c.m_ff / 32, MT16, M16);
+    a.epi = EPI_RES; a.R = s->u; a.RF = CB; a.ls = T.ls2;
+    a.Y = last ? s->tr_out : s->u; a.YF = CB; a.Ydstride = last ? 2 * s->tr_stride : 0; a.par = last ? s->frame : nullptr;
+    launch_gemm_h(st, a, PRE_NONE, T.ff2);
+  }
+  // strides of the frame-parity double buffers: the float buffers hold bf16, so a parity step of `stride` floats is
+  // 2 * stride bf16 elements
+  int mult = 8;
+  SITE("seanet.conv0");
+  a = mk_gemm(e->conv0, s->tr_out, CB, MT16, M16);
+  a.Xdstride = 2 * s->tr_stride; a.T = s->rows[0]; a.par = s->frame;
+  a.Y = s->a0; a.Ydstride = 2 * s->a0_stride; a.YF = mult * c.n_filters / 32; a.act = ACT_ELU;
+  launch_gemm_h(st, a, PRE_NONE, e->conv0);
+  const float *xin = s->a0;
+  long xds = 2 * s->a0_stride;
+  for (int i = 0; i < 3; ++i) {
+    const int cin = mult * c.n_filters, cout = cin / 2, hid = cout / c.compress;
+    const int Tin = s->rows[i], Tout = s->rows[i + 1];
+    const int MTin = B * Tin / 16, MTout = B * Tout / 16;
+    static const char *sn[3][3] = {{"seanet.convtr1", "seanet.res1a", "seanet.res1b"},
+                                   {"seanet.convtr2", "seanet.res2a", "seanet.res2b"},
+                                   {"seanet.convtr3", "seanet.res3a", "seanet.res3b"}};
+    SITE(sn[i][0]);
+    a = mk_gemm(e->convtr[i], xin, cin / 32, MTin, B * Tin);
+    a.Xdstride = xds; a.T = Tin; a.par = s->frame;
+    a.epi = EPI_CONVTR; a.cout = cout; a.stride = c.ratios[i];
+    a.Y = s->cbuf[i]; a.Ydstride = 2 * s->c_stride[i]; a.YF = cout / 32; a.act = ACT_ELU;
+    a.Yraw = s->craw[i]; a.Yrawdstride = 0;
+    launch_gemm_h(st, a, PRE_NONE, e->convtr[i]);
+    SITE(sn[i][1]);
+    a = mk_gemm(e->res_a[i], s->cbuf[i], cout / 32, MTout, B * Tout);
+    a.Xdstride = 2 * s->c_stride[i]; a.T = Tout; a.par = s->frame;
+    a.Y = s->rbuf[i]; a.YF = hid / 32; a.act = ACT_ELU;
+    launch_gemm_h(st, a, PRE_NONE, e->res_a[i]);
+    SITE(sn[i][2]);
+    a = mk_gemm(e->res_b[i], s->rbuf[i], hid / 32, MTout, B * Tout);
+    a.T = Tout; a.par = s->frame;
+    a.epi = EPI_RES; a.R = s->craw[i]; a.Rdstride = 0; a.RF = cout / 32; a.act = ACT_ELU;
+    a.Y = s->sbuf[i]; a.Ydstride = 2 * s->s_stride[i]; a.YF = cout / 32;
+    launch_gemm_h(st, a, PRE_NONE, e->res_b[i]);
+    xin = s->sbuf[i];
+    xds = 2 * s->s_stride[i];
+    mult /= 2;
+  }
+  const int Tl = s->rows[3];
+  SITE("seanet.conv_last");
+  a = mk_gemm(e->conv_last, xin, c.n_filters / 32, B * Tl / 16, B * Tl);
+  a.CF = c.n_filters / 32;
+  a.Xdstride = xds; a.T = Tl; a.par = s->frame;
+  a.epi = EPI_PCM; a.pcm = d_pcm ? d_pcm : s->pcm_dbg; a.pcm_i16 = s->pcm_i16;
+  {
+    ProfScope ps(st, "pcm_conv_h", 2.0 * a.M * c.n_filters + 4.0 * a.M, 2.0 * a.M * c.n_filters * c.last_kernel_size);
+    pcm_conv_h_kernel<<<cdiv(a.M, 256), 256, 0, st>>>(a, e->conv_last_w, e->conv_last_b);
+  }
+  SITE("mimi.tail");
+  {
+    ProfScope ps(st, "step_tail", 8.0 * B, 0);
+    step_tail_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->offset, B, st16, s->frame, nullptr);
+  }
+  SITE("");
+  return 0;
+}
+
 static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, const float *d_latent, float *d_pcm) {
+  if (e->codec_bf16) return mimi_enqueue_h(st, e, s, d_latent, d_pcm);
   const ptts_config &c = e->cfg;
   bind_engine(e);
   const int B = s->B, C = c.m_dim, CF = C / 16, LF = c.ldim / 16, st16 = c.upsample_stride;
@@ -1566,7 +1886,7 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
     const int nb_main = cdiv((long)B * (C / 4) * st16, 256);
     mimi_prologue_kernel<<<nb_main + cdiv(B * st16 * 32, 256), 256, 0, st>>>(
         d_latent, e->emb_std, e->emb_mean, e->quant_w, e->up_w, s->zq, s->zq_stride, s->frame, s->u0, B, c.ldim, C, st16,
-        nb_main, RopeArgs{s->offset, e->freq_mimi, s->rope, B * st16, st16});
+        nb_main, RopeArgs{s->offset, e->freq_mimi, s->rope, B * st16, st16}, 0);
   }
   GemmArgs a;
   const int M16 = B * st16;
@@ -2017,7 +2337,7 @@ extern "C" int ptts_timer_stop_ms(ptts_engine *e, void *stream, float *ms) {
   return 0;
 }
 extern "C" int64_t ptts_lm_weight_bytes(ptts_engine *e) { return e->lm_bytes; }
-extern "C" int64_t ptts_mimi_weight_bytes(ptts_engine *e) { return e->mimi_bytes; }
+extern "C" int64_t ptts_mimi_weight_bytes(ptts_engine *e) { return e->codec_bf16 ? e->mimi_bytes_h : e->mimi_bytes; }
 
 extern "C" int64_t ptts_debug_read(ptts_engine *e, void *state, int32_t is_mimi, const char *name, float *d_out,
                                    int64_t capacity, int32_t *rows, int32_t *cols, void *stream) {

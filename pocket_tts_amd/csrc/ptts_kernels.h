@@ -22,6 +22,17 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+// bf16 activations of the reduced-precision codec path (layout "FMH", see ptts_bf16.h)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4 to_bf16x4(f32x4 v) { return __builtin_convertvector(v, bf16x4); }
+__device__ __forceinline__ f32x4 from_bf16x4(bf16x4 v) { return __builtin_convertvector(v, f32x4); }
+// element offset (in bf16) of the 4 consecutive columns n0 .. n0 + 3 (n0 % 4 == 0) of row `row` in an FMH buffer with KB
+// 32-column blocks per row tile: lane (g, m) of fragment (row tile, block) holds 8 consecutive columns in 16 bytes
+__device__ __forceinline__ size_t fmh_off(size_t row, int n0, int KB) {
+  return (((row >> 4) * KB + (n0 >> 5)) * 64 + (((n0 & 31) >> 3) * 16 + (row & 15))) * 8 + (n0 & 7);
+}
+
 // Ablation switches for tests/hip/bench_gemm.hip only (timing builds; results are wrong when set):
 // 1 = no X loads, 2 = no W loads, 4 = no MFMA; gemm_lds_kernel: 8 = no DMA wait, 16 = no stage barrier, 32 = no DMA after the prologue;
 // gemm_kernel: 64 = no PRE_LNMOD statistics pass; 128 = GEMM and attention kernels return at once.
@@ -1142,7 +1153,7 @@ __global__ void prep_lm_kernel(const float *lat_in, const float *bos, const floa
 // The three tiny launches this replaces cost more in launch latency than in work.
 __global__ void mimi_prologue_kernel(const float *lat, const float *std, const float *mean, const float *wq,
                                      const float *wup, float *zq, long zdstride, const int *par_p, float *out, int B,
-                                     int ldim, int C, int s, int nb_main, RopeArgs rope) {
+                                     int ldim, int C, int s, int nb_main, RopeArgs rope, int h16) {
   if ((int)blockIdx.x >= nb_main) {
     rope_table_entry(rope, (blockIdx.x - nb_main) * blockDim.x + threadIdx.x);
     return;
@@ -1176,7 +1187,8 @@ __global__ void mimi_prologue_kernel(const float *lat, const float *std, const f
   o.z = zc.z * wup[(c + 2) * k2 + t] + zp.z * wup[(c + 2) * k2 + s + t];
   o.w = zc.w * wup[(c + 3) * k2 + t] + zp.w * wup[(c + 3) * k2 + s + t];
   const long m = (long)b * s + t;
-  *(f32x4 *)(out + (((size_t)(m >> 4) * CF + (c >> 4)) * 64 + 16 * ((c & 15) >> 2) + (m & 15)) * 4) = o;
+  if (h16) *(bf16x4 *)((__bf16 *)out + fmh_off((size_t)m, c, C / 32)) = to_bf16x4(o);
+  else *(f32x4 *)(out + (((size_t)(m >> 4) * CF + (c >> 4)) * 64 + 16 * ((c & 15) >> 2) + (m & 15)) * 4) = o;
 }
 
 __global__ void rope_table_kernel(const int *offset, const float *freq, float *tab, int M, int Tq) {
@@ -1267,6 +1279,7 @@ struct AttnArgs {
   float *part;  // [BH*QB][splits][16][64 + 2 (pad to 80)]
   float *Y;
   int YF;
+  int h16;  // output as bf16 FMH (YF = 32-column blocks) instead of fp32 FM
 };
 #define ATT_PSTRIDE 80
 
@@ -1284,7 +1297,8 @@ __device__ __forceinline__ void attn_store_out(const AttnArgs &a, int b, int h, 
       v.z = o[2][r] * linv_for_row[r];
       v.w = o[3][r] * linv_for_row[r];
       // column n = h*64 + 4c + j -> fragment 4h + c/4, k-group c%4
-      *(f32x4 *)(a.Y + (((m >> 4) * a.YF + 4 * h + (c >> 2)) * 64 + 16 * (c & 3) + (m & 15)) * 4) = v;
+      if (a.h16) *(bf16x4 *)((__bf16 *)a.Y + fmh_off(m, h * 64 + 4 * c, a.YF)) = to_bf16x4(v);
+      else *(f32x4 *)(a.Y + (((m >> 4) * a.YF + 4 * h + (c >> 2)) * 64 + 16 * (c & 3) + (m & 15)) * 4) = v;
     }
   }
 }
@@ -1577,7 +1591,8 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs a) {
   }
   O = O * (1.0f / L);
   const size_t m = (size_t)b * a.Tq + 16 * qb + qi;
-  *(f32x4 *)(a.Y + (((m >> 4) * a.YF + 4 * h + (c >> 2)) * 64 + 16 * (c & 3) + (m & 15)) * 4) = O;
+  if (a.h16) *(bf16x4 *)((__bf16 *)a.Y + fmh_off(m, h * 64 + 4 * c, a.YF)) = to_bf16x4(O);
+  else *(f32x4 *)(a.Y + (((m >> 4) * a.YF + 4 * h + (c >> 2)) * 64 + 16 * (c & 3) + (m & 15)) * 4) = O;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -154,12 +154,14 @@ class MimiState:
 class Engine:
     """Weights of one model on one GPU + entry points of the hot path."""
 
-    QUANT_GROUPS = {"attention": 1, "ffn": 2}  # PTTS_QUANT_* (include/ptts.h)
+    QUANT_GROUPS = {"attention": 1, "ffn": 2, "codec_bf16": 4}  # PTTS_QUANT_* / PTTS_CODEC_BF16 (include/ptts.h)
 
     def __init__(self, cfg: Config, weights: dict, device: str | torch.device = "cuda:0",
-                 quantize_groups: set | frozenset | None = None):
+                 quantize_groups: set | frozenset | None = None, _packed: str | None = None):
         """`quantize_groups`: subset of {"attention", "ffn"} (the keys of the reference's
-        quantization.apply_dynamic_int8): those Linear layers of the FlowLM transformer get int8 weights."""
+        quantization.apply_dynamic_int8): those Linear layers of the FlowLM transformer get int8 weights; plus
+        "codec_bf16": the Mimi decoder runs with bf16 weights / activations and fp32 accumulation (no reference
+        counterpart; BASELINE.json config #5)."""
         self.lib = _lib.load()
         self.handle = None
         self._states = weakref.WeakSet()
@@ -169,37 +171,43 @@ class Engine:
         if self.device.type != "cuda":
             raise RuntimeError("pocket_tts_amd runs on a ROCm GPU only (device must be cuda:N)")
         torch.cuda.set_device(self.device)
-        spec = state_dict_spec(cfg)
-        optional = set(mimi_encode_spec(cfg))  # checkpoints without voice cloning may lack the encoder
-        if any(n not in weights for n in optional):
-            spec = {k: v for k, v in spec.items() if k not in optional}
-        self.has_voice_encoder = all(n in weights for n in optional)
-        keep, arr = [], (_lib.PttsTensor * len(spec))()
-        for i, (name, shape) in enumerate(spec.items()):
-            if name not in weights:
-                raise KeyError(f"checkpoint is missing tensor {name}")
-            w = weights[name]
-            if isinstance(w, np.ndarray):
-                w = torch.from_numpy(w)
-            if tuple(w.shape) != tuple(shape):
-                raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(w.shape)}")
-            w = w.to(self.device, torch.float32).contiguous()
-            keep.append(w)
-            arr[i].name = name.encode()
-            arr[i].d_data = w.data_ptr()
-            arr[i].numel = w.numel()
-        torch.cuda.synchronize(self.device)
-        pc = make_ptts_config(cfg)
         h = C.c_void_p()
-        flags = 0
-        for g in quantize_groups or ():
-            if g not in self.QUANT_GROUPS:
-                raise ValueError(f"unknown quantization group {g!r} (this build supports {sorted(self.QUANT_GROUPS)})")
-            flags |= self.QUANT_GROUPS[g]
-        self.quantize_groups = frozenset(quantize_groups or ())
-        _lib.check(self.lib.ptts_create_ex(C.byref(pc), arr, len(spec), self.device.index or 0, flags, C.byref(h)))
+        if _packed is not None:
+            # a packed engine: the device images come from the file, `weights` holds only what stays on the Python side
+            self.has_voice_encoder = bool(weights.get("_has_voice_encoder", True))
+            self.quantize_groups = frozenset(quantize_groups or ())
+            _lib.check(self.lib.ptts_create_from_file(str(_packed).encode(), self.device.index or 0, C.byref(h)))
+        else:
+            spec = state_dict_spec(cfg)
+            optional = set(mimi_encode_spec(cfg))  # checkpoints without voice cloning may lack the encoder
+            if any(n not in weights for n in optional):
+                spec = {k: v for k, v in spec.items() if k not in optional}
+            self.has_voice_encoder = all(n in weights for n in optional)
+            keep, arr = [], (_lib.PttsTensor * len(spec))()
+            for i, (name, shape) in enumerate(spec.items()):
+                if name not in weights:
+                    raise KeyError(f"checkpoint is missing tensor {name}")
+                w = weights[name]
+                if isinstance(w, np.ndarray):
+                    w = torch.from_numpy(w)
+                if tuple(w.shape) != tuple(shape):
+                    raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(w.shape)}")
+                w = w.to(self.device, torch.float32).contiguous()
+                keep.append(w)
+                arr[i].name = name.encode()
+                arr[i].d_data = w.data_ptr()
+                arr[i].numel = w.numel()
+            torch.cuda.synchronize(self.device)
+            pc = make_ptts_config(cfg)
+            flags = 0
+            for g in quantize_groups or ():
+                if g not in self.QUANT_GROUPS:
+                    raise ValueError(f"unknown quantization group {g!r} (this build supports {sorted(self.QUANT_GROUPS)})")
+                flags |= self.QUANT_GROUPS[g]
+            self.quantize_groups = frozenset(quantize_groups or ())
+            _lib.check(self.lib.ptts_create_ex(C.byref(pc), arr, len(spec), self.device.index or 0, flags, C.byref(h)))
+            del keep
         self.handle = h
-        del keep
         # All work is queued on a torch-owned stream passed through the ABI's `stream` argument, so torch's
         # caching allocator (record_stream) and the library agree on one stream whose lifetime torch manages.
         self.stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("PTTS_PRIO_LM", "0")))
@@ -213,6 +221,37 @@ class Engine:
         self.bos_before_voice = None
         if "flow_lm.bos_before_voice" in weights:
             self.bos_before_voice = torch.as_tensor(weights["flow_lm.bos_before_voice"]).to(self.device, torch.float32)
+
+    # ---- packed-engine files (offline packer): device images + the few tensors the Python side keeps + the config
+    def save_packed(self, path):
+        """Writes `<path>` (device images, C ABI `ptts_engine_save`), `<path>.aux.safetensors` (embedding table,
+        bos_before_voice) and `<path>.yaml` (model config + weight format).  Load with `Engine.from_packed`."""
+        import safetensors.torch
+        import yaml
+
+        from .config import config_to_dict
+
+        _lib.check(self.lib.ptts_engine_save(self.handle, str(path).encode()))
+        aux = {"flow_lm.conditioner.embed.weight": self.embed.cpu().contiguous()}
+        if self.bos_before_voice is not None:
+            aux["flow_lm.bos_before_voice"] = self.bos_before_voice.cpu().contiguous()
+        safetensors.torch.save_file(aux, str(path) + ".aux.safetensors")
+        with open(str(path) + ".yaml", "w") as f:
+            yaml.safe_dump(dict(config=config_to_dict(self.cfg), quantize_groups=sorted(self.quantize_groups),
+                                has_voice_encoder=bool(self.has_voice_encoder)), f)
+
+    @classmethod
+    def from_packed(cls, path, device: str | torch.device = "cuda:0") -> "Engine":
+        """Engine from the files `save_packed` wrote: no checkpoint, no packing, no quantisation pass."""
+        import safetensors.torch
+        import yaml
+
+        from .config import config_from_dict
+
+        meta = yaml.safe_load(open(str(path) + ".yaml"))
+        aux = safetensors.torch.load_file(str(path) + ".aux.safetensors")
+        aux["_has_voice_encoder"] = meta["has_voice_encoder"]
+        return cls(config_from_dict(meta["config"]), aux, device, quantize_groups=set(meta["quantize_groups"]), _packed=str(path))
 
     # ---- stream ordering between torch's current stream and the engine stream
     def _pre(self):

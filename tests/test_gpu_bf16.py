@@ -1,0 +1,124 @@
+"""Reduced-precision codec (PTTS_CODEC_BF16: bf16 weights + activations, fp32 accumulate on bf16 MFMA) against this
+build's fp32 codec.  BASELINE.json config #5 has NO reference counterpart for the codec (docs/quantization.md:76: "Mimi
+is never quantized"), so parity is UNPINNED; quality is reported the way the reference's own quantisation harness
+does: SNR against the full-precision output (scripts/evaluate_quantization.py:215-228).  EOS decisions / frame counts
+come from the FlowLM, which stays fp32: they are identical by construction and checked end to end.  `-m gpu`."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import synth_weights
+from test_gpu_parity import dev
+
+pytestmark = pytest.mark.gpu
+
+
+def snr_db(ref, got):
+    ref, got = np.asarray(ref, np.float64), np.asarray(got, np.float64)
+    return 10 * np.log10((ref ** 2).sum() / max(((ref - got) ** 2).sum(), 1e-30))
+
+
+@pytest.mark.parametrize("cfg_name,B,nf", [("en100m", 2, 24), ("en100m", 5, 6), ("en100m", 64, 4)])
+def test_bf16_codec_snr_vs_fp32(cfg_name, B, nf):
+    from pocket_tts_amd.engine import Engine
+
+    cfg, W = synth_weights(cfg_name)
+    rng = np.random.default_rng(8)
+    lat = rng.standard_normal((nf, B, cfg.mimi.quantizer.dimension)).astype(np.float32)
+    outs = []
+    for groups in (None, {"codec_bf16"}):
+        eng = Engine(cfg, W, "cuda:0", quantize_groups=groups)
+        ms = eng.new_mimi_state(B)
+        pcm = [eng.mimi_decode(ms, dev(lat[f])).cpu().numpy() for f in range(nf)]
+        # a row reset in the middle (continuous batching): the per-sequence carries are cleared in both layouts
+        ms.reset_row(B - 1)
+        pcm += [eng.mimi_decode(ms, dev(lat[f])).cpu().numpy() for f in range(2)]
+        outs.append(np.stack(pcm))
+        eng.close()
+    ref, got = outs
+    assert np.isfinite(got).all()
+    s = snr_db(ref, got)
+    print(f"{cfg_name} B={B}: bf16 codec SNR {s:.1f} dB vs fp32 over {nf + 2} frames")
+    assert s > 30.0, s  # bf16 has 8 significant bits per operand; ~40 dB typical
+    # after the row reset, the reset row reproduces its own first frames (carries really cleared)
+    a = snr_db(got[0][B - 1], got[nf][B - 1])
+    assert a > 60.0, a
+
+
+def test_bf16_codec_needs_32_channel_multiples():
+    """the tiny test config has 16-channel SEANet layers: the bf16 path (32-wide MFMA k-blocks) refuses it loudly"""
+    from pocket_tts_amd._lib import PttsError
+    from pocket_tts_amd.engine import Engine
+
+    cfg, W = synth_weights("tiny")
+    with pytest.raises(PttsError, match="multiple of 32"):
+        Engine(cfg, W, "cuda:0", quantize_groups={"codec_bf16"})
+
+
+def test_bf16_codec_end_to_end_frame_counts():
+    """TTSModel(codec_bf16=True) on the full-size model: same EOS decisions / frame count as the fp32 model (the
+    FlowLM is untouched), waveform SNR as reported by the reference's quantisation harness"""
+    from pathlib import Path
+
+    from pocket_tts_amd import TTSModel
+
+    G = Path(__file__).parent / "golden"
+    text = "Hello world. This is a test."
+    wavs = []
+    for flag in (False, True):
+        m = TTSModel.load_model(config=G / "e2e2_en100m.yaml", temp=0.0, codec_bf16=flag)
+        st = m.get_state_for_conditioning(torch.randn(1, 12, 1024, generator=torch.Generator().manual_seed(3)) * 0.1)
+        wavs.append(m.generate_audio(st, text, frames_after_eos=2).numpy())
+        m.engine.close()
+    assert wavs[0].shape == wavs[1].shape and wavs[0].shape[0] >= 1920
+    s = snr_db(wavs[0], wavs[1])
+    print(f"end to end ({wavs[0].shape[0] // 1920} frames): bf16 codec SNR {s:.1f} dB vs fp32")
+    assert s > 25.0
+
+
+@pytest.mark.parametrize("cfg_name,groups", [("tiny", None), ("tiny", {"attention", "ffn"}),
+                                             ("en100m", {"attention", "ffn", "codec_bf16"})])
+def test_packed_engine_roundtrip(tmp_path, cfg_name, groups):
+    """Offline packer: an engine rebuilt from its packed file (no checkpoint, no packing / quantisation pass)
+    reproduces the original engine bit for bit, for the fp32 and for the int8 + bf16 weight formats."""
+    from pocket_tts_amd.engine import Engine
+
+    cfg, W = synth_weights(cfg_name)
+    rng = np.random.default_rng(3)
+    B, T, ns = 2, 9, 4
+    emb = dev((rng.standard_normal((B, T, cfg.flow_lm.transformer.d_model)) * 0.5).astype(np.float32))
+    audio = torch.from_numpy((rng.standard_normal(24000) * 0.1).astype(np.float32))
+
+    def run(eng):
+        st, ms = eng.new_lm_state(B, T + ns), eng.new_mimi_state(B)
+        eng.lm_prefill(st, emb)
+        out = []
+        for _ in range(ns):
+            o, lg, _ = eng.lm_decode_step(st, None, None, 1, -4.0)
+            out.append((o.cpu().numpy(), lg.cpu().numpy(), eng.mimi_decode(ms, o).cpu().numpy()))
+        tok = eng.embed_text(torch.tensor([[1, 2, 3]])).cpu().numpy()
+        cond = eng.encode_voice(audio)[1].cpu().numpy()
+        return out, tok, cond
+
+    a = Engine(cfg, W, "cuda:0", quantize_groups=groups)
+    ref = run(a)
+    path = tmp_path / "model.ptts"
+    a.save_packed(path)
+    a.close()
+    b = Engine.from_packed(path)
+    assert b.quantize_groups == frozenset(groups or ()) and b.has_voice_encoder
+    got = run(b)
+    b.close()
+    for (o, lg, p), (o2, lg2, p2) in zip(ref[0], got[0]):
+        assert np.array_equal(o, o2) and np.array_equal(lg, lg2) and np.array_equal(p, p2)
+    assert np.array_equal(ref[1], got[1]) and np.array_equal(ref[2], got[2])
+    # a file of another library layout is refused, not loaded
+    raw = bytearray(path.read_bytes())
+    raw[8] ^= 0x7F
+    bad = tmp_path / "bad.ptts"
+    bad.write_bytes(bytes(raw))
+    for suffix in (".yaml", ".aux.safetensors"):
+        (tmp_path / ("bad.ptts" + suffix)).write_bytes((tmp_path / ("model.ptts" + suffix)).read_bytes())
+    with pytest.raises(Exception):
+        Engine.from_packed(bad)

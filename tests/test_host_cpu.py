@@ -1,5 +1,6 @@
 """CPU checks of the host logic: config schema, weight inventory, WAV writer."""
 
+import sys
 import wave
 
 import numpy as np
@@ -132,3 +133,22 @@ def test_bench_presets_and_rank_spawning():
                            capture_output=True, text=True, timeout=300)
         assert r.returncode != 0
         assert "rank 0 exited" in r.stderr and "rank 1 exited" in r.stderr
+
+
+def test_drop_in_package_name():
+    """`import pocket_tts` is the drop-in: the reference exports exactly TTSModel and export_model_state
+    (pocket_tts/__init__.py:6-19; its tests/test_python_api.py:8-26 checks `__all__`), and `pocket_tts.main:cli_app`
+    is the console-script entry point (pyproject.toml:71-72)."""
+    import importlib
+
+    sys.modules.pop("pocket_tts", None)
+    m = importlib.import_module("pocket_tts")
+    assert "pocket_tts_amd" not in m.__file__ and m.__file__.endswith("pocket_tts/__init__.py")
+    assert sorted(m.__all__) == ["TTSModel", "export_model_state"]
+    import pocket_tts_amd
+
+    assert m.TTSModel is pocket_tts_amd.TTSModel and m.export_model_state is pocket_tts_amd.export_model_state
+    main = importlib.import_module("pocket_tts.main")
+    assert callable(main.cli_app)
+    with pytest.raises(SystemExit):
+        main.cli_app(["generate", "--help"])
