@@ -1519,6 +1519,8 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
   a.epi = EPI_HEAD; a.Y = s->ce; a.YF = FDF; a.head_nt = FDF; a.eos_thr = eos_thr;
   a.eos_logit = s->eos_logit; a.is_eos = s->is_eos;
   a.eos_logit2 = d_eos_logit; a.is_eos2 = d_is_eos;  // caller's buffers are written by the epilogue itself
+  const bool silu_in_head = lsd_steps == 1;  // s->ce then holds silu(t_emb + cond) and the modulation GEMM loads it as is
+  if (silu_in_head) { a.act = ACT_SILU; a.prevec = tcomb; }
   launch_gemm(st, a, PRE_LNFOLD);
   const int AF = e->adaln.NT;
   if (flow_cluster_ok(e, s) && lsd_steps <= s->flow_steps) {
@@ -1528,7 +1530,7 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
       SITE("flow.adaln");
       a = mk_gemm(e->adaln, s->ce, FDF, MT, B);
       a.prevec = tcomb + (size_t)i * FD; a.Y = s->mod + (size_t)i * MT * 256 * AF; a.YF = AF;
-      launch_gemm(st, a, PRE_ADDSILU);
+      launch_gemm(st, a, silu_in_head ? PRE_NONE : PRE_ADDSILU);
     }
     SITE("flow.cluster");
     launch_flow_cluster(st, e, s, lsd_steps, d_latent_out);
@@ -1538,7 +1540,7 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
     SITE("flow.adaln");
     a = mk_gemm(e->adaln, s->ce, FDF, MT, B);
     a.prevec = tcomb + (size_t)i * FD; a.Y = s->mod; a.YF = AF;
-    launch_gemm(st, a, PRE_ADDSILU);
+    launch_gemm(st, a, silu_in_head ? PRE_NONE : PRE_ADDSILU);
     SITE("flow.input_proj");
     a = mk_gemm(e->input_proj, s->latfm, LF, MT, B);
     a.Y = s->fx; a.YF = FDF;

@@ -249,6 +249,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 acc, int 
     } break;
     case EPI_HEAD: {
       if (nt < a.head_nt) {
+        // with a single LSD step the AdaLN input silu(t_emb + cond_embed(c)) (mlp.py:107,127,210) is formed here, once,
+        // instead of on every operand load of the 640-tile modulation GEMM
+        if (a.act == ACT_SILU) acc = act4(acc + *(const f32x4 *)(a.prevec + n0), ACT_SILU);
         *(f32x4 *)(a.Y + (((size_t)mt * a.YF + nt) * 64 + lane) * 4) = acc;
       } else if (g == 0 && m < a.M) {
         const uint8_t fl = acc.x > a.eos_thr ? 1 : 0;
