@@ -196,7 +196,7 @@ def first_chunk_latency(eng, args, job1):
         job1.start_utterances()
         job1.pipe.step()
         f = job1.pipe.flush()
-        job1.pipe.ev[f & 1].synchronize()
+        job1.pipe.done_event(f).synchronize()
         dt = (time.perf_counter() - t0) * 1e3
         if t >= 5:
             eng_ms.append(dt)

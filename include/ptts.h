@@ -187,6 +187,9 @@ int ptts_tune_import(ptts_engine *e, const char *text);
 /* Engine options (experiments / A-B tests; defaults come from the environment variable in brackets):
  *   "flow_cluster"  [PTTS_FLOW_CLUSTER, 1]  1 = the flow MLP of a decode step runs as ONE cooperative launch
  *                                           (ptts_flow.h), 0 = one GEMM launch per layer
+ *   "lm_cluster"    [PTTS_LM_CLUSTER, 0]    1 = all transformer layers of a decode step run as ONE cooperative launch
+ *                                           (ptts_lm.h; fp32 weights only; correct, but measured SLOWER than the default:
+ *                                           DESIGN.md section 3), 0 = five launches per layer
  *   "k_rotate"      [PTTS_K_ROTATE, 0]      1 = K-split GEMM workgroups start their K loop at a column-block dependent
  *                                           chunk (spreads the re-reads of the shared activation rows over L2 channels)
  * Applies to steps enqueued / graphs captured after the call.  Returns -1 for an unknown key. */

@@ -202,8 +202,8 @@ class ContinuousBatcher:
     def _route(self, frame: int):
         """hand the rows of decoded `frame` to their requests"""
         pipe = self.pipe
-        pipe.ev[frame & 1].synchronize()
-        pcm = pipe.pcm16[frame & 1] if self.pcm_format == "i16" else pipe.pcm_of(frame)
+        pipe.done_event(frame).synchronize()
+        pcm = pipe.pcm16_of(frame) if self.pcm_format == "i16" else pipe.pcm_of(frame)
         for b in range(self.B):
             for job in self.history[b]:
                 if job.start is None or frame < job.start:

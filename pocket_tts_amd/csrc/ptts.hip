@@ -3,6 +3,7 @@
 #include "ptts_kernels.h"
 #include "ptts_flow.h"
 #include "ptts_bf16.h"
+#include "ptts_lm.h"
 
 #include <algorithm>
 #include <array>
@@ -121,6 +122,8 @@ struct ptts_engine {
   struct Tuner *tuner = nullptr;
   Profiler prof;
   int opt_flow_cluster = 1;
+  int opt_lm_cluster = 0;  // measured slower than five launches per layer: kept as an experiment
+  LmLayerP *lm_table = nullptr;  // device table of the FlowLM layers for lm_cluster_kernel (null: not eligible)
   int opt_k_rotate = 0;
   std::recursive_mutex mu;  // entry points that enqueue work or touch tuner / profiler / LSD tables hold it
   int quant_flags = 0;
@@ -147,6 +150,9 @@ struct ptts_lm_state {
   unsigned long long *fflags = nullptr;
   int *ferr = nullptr;
   int flow_steps = 0, flow_rt = 1, flow_ng = 1;
+  // single-launch transformer stack (lm_cluster_kernel): exchange slots + flags, allocated on first use
+  float *lexch = nullptr;
+  unsigned long long *lflags = nullptr;
   float *lat, *lat_prev;  // plain [B][ldim]
   float *eos_logit;
   uint8_t *is_eos;
@@ -797,6 +803,7 @@ extern "C" int ptts_create_ex(const ptts_config *cfg, const ptts_tensor *tensors
   e->tuner = new Tuner();
   e->quant_flags = quant_flags;
   if (const char *v = getenv("PTTS_FLOW_CLUSTER")) e->opt_flow_cluster = atoi(v) != 0;
+  if (const char *v = getenv("PTTS_LM_CLUSTER")) e->opt_lm_cluster = atoi(v) != 0;
   if (const char *v = getenv("PTTS_K_ROTATE")) e->opt_k_rotate = atoi(v) != 0;
   const int rc = build_engine(e, tensors, n);
   if (rc < 0) {  // missing / ill-shaped tensor, HIP error: release what was built so far
@@ -859,6 +866,23 @@ static int build_engine(ptts_engine *e, const ptts_tensor *tensors, int32_t n) {
   e->lm_bytes = e->in_linear.bytes() + e->head.bytes() + e->adaln.bytes() + e->input_proj.bytes() + e->fin.bytes();
   for (auto &L : e->lm) e->lm_bytes += L.qkv.bytes() + L.out.bytes() + L.ff1.bytes() + L.ff2.bytes();
   for (auto &R : e->res) e->lm_bytes += R.l0.bytes() + R.l2.bytes();
+  {
+    // layer table of the single-launch transformer stack: fp32 weights, no LayerScale, head dim 64 (4 column tiles per
+    // head), linear1 at most 4 column tiles per workgroup
+    const int DF = D / 16, FFF = c.ff_dim / 16;
+    bool ok = DF <= 64 && DF % 4 == 0 && c.num_heads * 4 == DF && FFF % DF == 0 && FFF / DF <= 4 && c.num_layers <= 64;
+    for (auto &L : e->lm) ok = ok && !L.qkv.wq && !L.out.wq && !L.ff1.wq && !L.ff2.wq && !L.ls1 && !L.ls2 && L.qkv.ln_s && L.ff1.ln_s;
+    if (ok) {
+      std::vector<LmLayerP> h(c.num_layers);
+      for (int l = 0; l < c.num_layers; ++l) {
+        const TrLayer &T = e->lm[l];
+        h[l] = LmLayerP{T.qkv.w, T.qkv.ln_s, T.qkv.ln_c, T.out.w, T.ff1.w, T.ff1.ln_s, T.ff1.ln_c, T.ff2.w};
+      }
+      CHK(dalloc(e, (void **)&e->lm_table, h.size() * sizeof(LmLayerP)));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      HIPCHK(hipMemcpy(e->lm_table, h.data(), h.size() * sizeof(LmLayerP), hipMemcpyHostToDevice));
+    }
+  }
 
   // ---- Mimi decode side
   CHK(copy_vec(e, p + "emb_std", c.ldim, &e->emb_std));
@@ -1185,7 +1209,7 @@ extern "C" void ptts_lm_state_destroy(ptts_lm_state *s) {
   if (s->pre.x) free_scratch(&s->pre);
   hipFree(s->xlat); hipFree(s->latfm); hipFree(s->c); hipFree(s->ce); hipFree(s->mod); hipFree(s->fx);
   hipFree(s->fh); hipFree(s->f1); hipFree(s->lat); hipFree(s->lat_prev); hipFree(s->eos_logit); hipFree(s->is_eos); hipFree(s->rng_ctr); hipFree(s->active); hipFree(s->fstat);
-  hipFree(s->fexch); hipFree(s->fflags); hipFree(s->ferr);
+  hipFree(s->fexch); hipFree(s->fflags); hipFree(s->ferr); hipFree(s->lexch); hipFree(s->lflags);
   delete s;
 }
 
@@ -1441,6 +1465,65 @@ static void launch_flow_cluster(hipStream_t st, ptts_engine *e, ptts_lm_state *s
   launch_flow_rt<1>(st, fa, kpw);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Single-launch transformer stack (ptts_lm.h)
+static constexpr int kLmMaxWGs = 256;  // resident workgroups of one launch (one per CU)
+static bool lm_cluster_ok(const ptts_engine *e, const ptts_lm_state *s) {
+  if (!e->opt_lm_cluster || !e->lm_table) return false;
+  return (double)s->kv_plane() * 4.0 < 2.0e9;  // 32-bit buffer offsets into a K / V plane
+}
+static int ensure_lm_cluster(ptts_engine *e, ptts_lm_state *s, hipStream_t st) {
+  if (s->lexch || !e->lm_table) return 0;
+  const ptts_config &c = e->cfg;
+  const int DF = c.d_model / 16, FFF = c.ff_dim / 16;
+  AllocScope alloc_scope(st);
+  CHK(dallocT(nullptr, &s->lexch, (size_t)s->MT * c.num_layers * (4 * DF + FFF) * 256));
+  CHK(dallocT(nullptr, &s->lflags, (size_t)s->MT * c.num_layers * 5 * DF));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+static void launch_lm_cluster(hipStream_t st, ptts_engine *e, ptts_lm_state *s, Scratch &sc) {
+  const ptts_config &c = e->cfg;
+  LmArgs la;
+  memset(&la, 0, sizeof la);
+  la.MT = s->MT; la.M = s->B; la.NG = s->MT; la.DF = c.d_model / 16; la.FFF = c.ff_dim / 16; la.H = c.num_heads;
+  la.NCL = std::max(1, std::min(la.NG, kLmMaxWGs / la.DF));
+  la.L = c.num_layers; la.cap = s->cap;
+  la.layers = e->lm_table; la.kv = s->kv; la.kv_plane = (long)s->kv_plane();
+  la.offset = s->offset; la.freq = e->freq_lm; la.x = sc.x; la.exch = s->lexch; la.flags = s->lflags;
+  la.ctr = s->rng_ctr; la.err = s->ferr; la.ln_eps = 1e-5f;
+  double keys = 0;
+  for (int b = 0; b < s->B; ++b) keys += s->h_off[b] + 1;
+  const double wbytes = 4.0 * 256.0 * c.num_layers * ((double)4 * la.DF * la.DF + 2.0 * la.DF * la.FFF);
+  ProfScope ps(st, "lm_cluster@" + std::to_string((long)la.NCL * la.DF * FLOW_THREADS),
+               wbytes + c.num_layers * keys * c.num_heads * 64 * 4 * 2,
+               c.num_layers * (2.0 * s->B * 256.0 * ((double)4 * la.DF * la.DF + 2.0 * la.DF * la.FFF) + 4.0 * keys * c.num_heads * 64));
+  lm_cluster_kernel<0><<<dim3(la.NCL * la.DF), dim3(FLOW_THREADS), 0, st>>>(la);
+}
+
+// Cooperative kernels (flow / transformer clusters) need all their workgroups resident; two of them running at the same
+// time on one GPU (two states stepped from two streams) could starve each other.  Every step that contains them is
+// therefore chained behind the previous such step of the same DEVICE with an event (GPU-side order, no host wait).
+static std::mutex g_coop_mu;
+static hipEvent_t g_coop_ev[64] = {};
+struct CoopGuard {
+  int dev;
+  hipStream_t st;
+  bool on;
+  CoopGuard(int device, hipStream_t stream, bool enabled) : dev(device & 63), st(stream), on(enabled) {
+    if (!on) return;
+    g_coop_mu.lock();
+    if (!g_coop_ev[dev]) (void)hipEventCreateWithFlags(&g_coop_ev[dev], hipEventDisableTiming);
+    else (void)hipStreamWaitEvent(st, g_coop_ev[dev], 0);
+  }
+  ~CoopGuard() {
+    if (!on) return;
+    if (g_coop_ev[dev]) (void)hipEventRecord(g_coop_ev[dev], st);
+    g_coop_mu.unlock();
+  }
+};
+
 static void lm_layers(hipStream_t st, ptts_engine *e, ptts_lm_state *s, Scratch &sc, int M, int Tq, bool rope_done = false) {
   const ptts_config &c = e->cfg;
   bind_engine(e);
@@ -1513,7 +1596,12 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
   GemmArgs a = mk_gemm(e->in_linear, s->xlat, LF, MT, B);
   a.Y = sc.x; a.YF = DF;
   launch_gemm(st, a, PRE_NONE);
-  lm_layers(st, e, s, sc, B, 1, true);
+  if (lm_cluster_ok(e, s) && s->lexch) {
+    SITE("lm.cluster");
+    launch_lm_cluster(st, e, s, sc);
+  } else {
+    lm_layers(st, e, s, sc, B, 1, true);
+  }
   SITE("flow.head");  // out_norm is folded into [cond_embed ; out_eos]
   a = mk_gemm(e->head, sc.x, DF, MT, B);
   a.epi = EPI_HEAD; a.Y = s->ce; a.YF = FDF; a.head_nt = FDF; a.eos_thr = eos_thr;
@@ -1589,9 +1677,13 @@ extern "C" int ptts_lm_decode_step(ptts_engine *e, ptts_lm_state *s, const float
   HIPCHK(hipSetDevice(e->device));
   CHK(prepare_lsd(e, lsd_steps));
   CHK(ensure_flow(e, s, lsd_steps, S(e, stream)));
+  CHK(ensure_lm_cluster(e, s, S(e, stream)));
   for (int b = 0; b < s->B; ++b)
     if (s->h_off[b] + 1 > s->cap) return fail(-5, "decode: KV cache capacity exceeded");
-  CHK(lm_step_enqueue(S(e, stream), e, s, d_latent_in, d_noise, lsd_steps, eos_threshold, d_latent_out, d_eos_logit, d_is_eos));
+  {
+    CoopGuard guard(e->device, S(e, stream), e->opt_lm_cluster || e->opt_flow_cluster);
+    CHK(lm_step_enqueue(S(e, stream), e, s, d_latent_in, d_noise, lsd_steps, eos_threshold, d_latent_out, d_eos_logit, d_is_eos));
+  }
   for (int b = 0; b < s->B; ++b) s->h_off[b] += s->h_active[b];
   HIPCHK(hipGetLastError());
   return 0;
@@ -2197,6 +2289,7 @@ extern "C" int ptts_graph_capture_lm_step(ptts_engine *e, ptts_lm_state *s, cons
   HIPCHK(hipSetDevice(e->device));
   CHK(prepare_lsd(e, lsd_steps));
   CHK(ensure_flow(e, s, lsd_steps, e->stream));
+  CHK(ensure_lm_cluster(e, s, e->stream));
   ptts_graph *g = new ptts_graph();
   g->lm = s;
   CHK(capture(e, g, [&](hipStream_t st) {
@@ -2228,6 +2321,7 @@ extern "C" int ptts_graph_capture_pipelined(ptts_engine *e, ptts_lm_state *s, pt
   HIPCHK(hipSetDevice(e->device));
   CHK(prepare_lsd(e, lsd_steps));
   CHK(ensure_flow(e, s, lsd_steps, e->stream));
+  CHK(ensure_lm_cluster(e, s, e->stream));
   ptts_graph *g = new ptts_graph();
   g->lm = s;
   g->mimi = m;
@@ -2262,7 +2356,10 @@ extern "C" int ptts_graph_launch(ptts_graph *g, void *stream) {
     for (int b = 0; b < g->lm->B; ++b)
       if (g->lm->h_off[b] + 1 > g->lm->cap) return fail(-5, "decode: KV cache capacity exceeded");
   }
-  HIPCHK(hipGraphLaunch(g->exec, S(e, stream)));
+  {
+    CoopGuard guard(e->device, S(e, stream), g->lm != nullptr);
+    HIPCHK(hipGraphLaunch(g->exec, S(e, stream)));
+  }
   if (g->lm) for (int b = 0; b < g->lm->B; ++b) g->lm->h_off[b] += g->lm->h_active[b];
   if (g->mimi) g->mimi->h_frame += 1;
   return 0;
@@ -2282,6 +2379,7 @@ extern "C" int ptts_set_option(ptts_engine *e, const char *key, int32_t value) {
   ENGINE_LOCK(e);
   const std::string k(key);
   if (k == "flow_cluster") e->opt_flow_cluster = value != 0;
+  else if (k == "lm_cluster") e->opt_lm_cluster = value != 0;
   else if (k == "k_rotate") e->opt_k_rotate = value != 0;
   else return fail(-1, "unknown option " + k);
   return 0;

@@ -494,35 +494,39 @@ class StepPipeline:
         self.eng, self.st, self.ms = eng, lm_state, mimi_state
         B, dev = lm_state.batch, eng.device
         self.mode = mode or ("hostsync" if B <= 8 else "events")
-        self.lat = [torch.zeros(B, eng.ldim, device=dev) for _ in range(2)]
-        self.logit = [torch.empty(B, device=dev) for _ in range(2)]
-        self.flag = [torch.zeros(B, dtype=torch.uint8).pin_memory() for _ in range(2)]  # EOS flags land on the host
-        self.pcm = [torch.zeros(B, eng.frame_samples).pin_memory() for _ in range(2)]
-        self.ev = [torch.cuda.Event() for _ in range(2)]    # codec frame (f & 1) complete -> pcm_of(f) valid
-        self.ev_lm = [torch.cuda.Event() for _ in range(2)]  # FlowLM step (t & 1) complete -> flag valid
+        # ring of output buffers (latent -> codec input, EOS flags, PCM).  Throughput mode keeps 4 so that the FlowLM
+        # stream may run up to 3 steps ahead of the codec stream (with 2 the two streams move in lock-step and every
+        # hiccup of one stalls the other); the latency modes need only 2.
+        self.nb = nb = 4 if self.mode == "events" else 2
+        self.lat = [torch.zeros(B, eng.ldim, device=dev) for _ in range(nb)]
+        self.logit = [torch.empty(B, device=dev) for _ in range(nb)]
+        self.flag = [torch.zeros(B, dtype=torch.uint8).pin_memory() for _ in range(nb)]  # EOS flags land on the host
+        self.pcm = [torch.zeros(B, eng.frame_samples).pin_memory() for _ in range(nb)]
+        self.ev = [torch.cuda.Event() for _ in range(nb)]    # codec frame (f % nb) complete -> pcm_of(f) valid
+        self.ev_lm = [torch.cuda.Event() for _ in range(nb)]  # FlowLM step (t % nb) complete -> flag valid
         self.s2 = torch.cuda.Stream(device=dev, priority=int(os.environ.get("PTTS_PRIO_CODEC", "0")))
         eng.sync()
         torch.cuda.synchronize(dev)
         eng.tune(B)  # before capture: graphs freeze the tile choices
         lib, H = eng.lib, eng.handle
         self.g_first = [eng.capture_lm_step(lm_state, noise, lsd_steps, eos_threshold, self.lat[p], self.logit[p],
-                                            self.flag[p]) for p in range(2)]
+                                            self.flag[p]) for p in range(nb)]
         # optional 16-bit PCM beside the fp32 one (the WAV sample format, data/audio.py:79), also pinned
-        self.pcm16 = [torch.zeros(B, eng.frame_samples, dtype=torch.int16).pin_memory() for _ in range(2)] if pcm_i16 else None
+        self.pcm16 = [torch.zeros(B, eng.frame_samples, dtype=torch.int16).pin_memory() for _ in range(nb)] if pcm_i16 else None
         self.g_last = []
-        for p in range(2):
+        for p in range(nb):
             mimi_state.set_pcm_i16(self.pcm16[p] if pcm_i16 else None)
             self.g_last.append(eng.capture_mimi(mimi_state, self.lat[p], self.pcm[p]))
         mimi_state.set_pcm_i16(None)
         self.g_both = []
         if self.mode == "fork":
-            for p in range(2):
+            for p in range(nb):
                 g = C.c_void_p()
                 _lib.check(lib.ptts_graph_capture_pipelined(
                     H, lm_state.handle, mimi_state.handle, _ptr(noise), lsd_steps, eos_threshold, _ptr(self.lat[p]),
                     _ptr(self.logit[p]), _ptr(self.flag[p]), _ptr(self.lat[p ^ 1]), _ptr(self.pcm[p ^ 1]), C.byref(g)))
                 self.g_both.append(g)
-        for p in range(2):
+        for p in range(nb):
             self.ev[p].record(self.s2)
         self.t = 0          # FlowLM steps launched for the current utterances
         self.decoded = 0    # codec frames launched
@@ -531,15 +535,18 @@ class StepPipeline:
         """new utterances: flush the pending frame, codec state back to zero carries"""
         self.flush()
         if self.mode != "fork":
-            self.s2.synchronize()
-        self.ms.reset()
+            # zero carries on the CODEC stream: ordered behind the frames already queued there and ahead of the next
+            # utterance's first frame, off the FlowLM stream's critical path (clone + prefill + first step)
+            self.ms.reset(self.s2)
+        else:
+            self.ms.reset()
         self.t = 0
         self.decoded = 0
 
     def _decode_pending(self):
         """hostsync mode: wait for FlowLM step t-1 on the host, then start its codec frame on stream 2"""
         f = self.decoded
-        q = f & 1
+        q = f % self.nb
         self.ev_lm[q].synchronize()
         self.eng.graph_launch(self.g_last[q], self.s2)
         self.ev[q].record(self.s2)
@@ -548,9 +555,9 @@ class StepPipeline:
 
     def step(self):
         """Launch FlowLM step t and the decode of frame t-1.  Returns the index of the frame whose PCM is
-        complete when `ev[frame & 1]` fires (None for the first step).  After the call,
-        `flag[(t-1) & 1]` (hostsync mode) holds the EOS flags of step t-1."""
-        eng, p = self.eng, self.t & 1
+        complete when `done_event(frame)` fires (None for the first step).  After the call,
+        `flag[(t-1) % nb]` (hostsync mode) holds the EOS flags of step t-1."""
+        eng, p = self.eng, self.t % self.nb
         done = None
         if self.mode == "fork":
             if self.decoded < self.t:
@@ -581,7 +588,7 @@ class StepPipeline:
     # ---- building blocks for a host-driven loop with an EOS decision per step (TTSModel) ----------
     def lm_step_async(self) -> int:
         """launch FlowLM step t on stream 1; returns t"""
-        p = self.t & 1
+        p = self.t % self.nb
         self.eng.stream.wait_event(self.ev[p])  # frame t-2 decoded: lat[p] may be overwritten
         self.eng.graph_launch(self.g_first[p])
         self.ev_lm[p].record(self.eng.stream)
@@ -590,12 +597,12 @@ class StepPipeline:
 
     def wait_flags(self, step: int) -> torch.Tensor:
         """host waits for FlowLM step `step`; returns its EOS flags u8[B] (pinned host memory)"""
-        self.ev_lm[step & 1].synchronize()
-        return self.flag[step & 1]
+        self.ev_lm[step % self.nb].synchronize()
+        return self.flag[step % self.nb]
 
     def decode_async(self, frame: int):
         """launch the codec decode of `frame` on stream 2 (call after wait_flags(frame))"""
-        q = frame & 1
+        q = frame % self.nb
         self.eng.graph_launch(self.g_last[q], self.s2)
         self.ev[q].record(self.s2)
         self.decoded = frame + 1
@@ -606,15 +613,22 @@ class StepPipeline:
             return None
         if self.mode == "hostsync":
             return self._decode_pending()
-        p = (self.t - 1) & 1
+        p = (self.t - 1) % self.nb
         self.eng.graph_launch(self.g_last[p])
         self.ev[p].record(self.eng.stream)
         self.decoded += 1
         return self.decoded - 1
 
     def pcm_of(self, frame: int) -> torch.Tensor:
-        """host tensor [B, frame_samples] of `frame` (valid after ev[frame & 1].synchronize())"""
-        return self.pcm[frame & 1]
+        """host tensor [B, frame_samples] of `frame` (valid after `done_event(frame).synchronize()`)"""
+        return self.pcm[frame % self.nb]
+
+    def done_event(self, frame: int):
+        """event that fires when the codec decode of `frame` (PCM in `pcm_of(frame)`) is complete"""
+        return self.ev[frame % self.nb]
+
+    def pcm16_of(self, frame: int) -> torch.Tensor:
+        return self.pcm16[frame % self.nb]
 
     def sync(self):
         self.eng.stream.synchronize()

@@ -288,7 +288,7 @@ class TTSModel:
 
     @staticmethod
     def _collect(pipe, frame, chunks, n_emit):
-        pipe.ev[frame & 1].synchronize()
+        pipe.done_event(frame).synchronize()
         pcm = pipe.pcm_of(frame)
         for b in range(len(chunks)):
             if n_emit[b] is None or frame < n_emit[b]:
@@ -363,7 +363,7 @@ class TTSModel:
             yielded = 0    # frames handed to the caller
 
             def pop(frame):
-                pipe.ev[frame & 1].synchronize()
+                pipe.done_event(frame).synchronize()
                 return pipe.pcm_of(frame)[0].clone()
 
             for step in range(max_gen_len):

@@ -138,3 +138,98 @@ def test_two_engines_two_threads_are_independent():
     finally:
         ea.close()
         eb.close()
+
+
+# ---- the transformer stack as one launch (csrc/ptts_lm.h) ----------------------------------------------------------
+@pytest.mark.parametrize("cfg_name,B,ctx", [("tiny", 3, 20), ("tiny", 37, 5), ("en100m", 1, 40), ("en100m", 5, 170),
+                                            ("en100m", 64, 33), ("en100m", 100, 20), ("24l", 32, 24)])
+def test_lm_cluster_matches_per_layer_launches(cfg_name, B, ctx):
+    """latents, EOS logits AND the KV rows written by the single-launch transformer stack against five launches per
+    layer (fp32 summation order differs: K-split over 8 waves instead of 4)"""
+    eng = get_engine(cfg_name)
+    steps = 5
+    out = {}
+    for opt in (0, 1):
+        eng.set_option("lm_cluster", opt)
+        rng = np.random.default_rng(17)
+        st = eng.new_lm_state(B, ctx + steps + 1)
+        eng.lm_prefill(st, dev((rng.standard_normal((B, ctx, eng.D)) * 0.3).astype(np.float32)))
+        lat = []
+        for i in range(steps):
+            noise = dev((rng.standard_normal((B, eng.ldim)) * 0.8).astype(np.float32))
+            o, lg, _ = eng.lm_decode_step(st, None, noise, 1, -4.0)
+            lat.append((o.cpu().numpy(), lg.cpu().numpy()))
+        assert not st.error()
+        kv = [st.export_layer(l, ctx + steps).cpu().numpy()[:, :, ctx:] for l in (0, eng.L - 1)]
+        out[opt] = (lat, kv, list(st.offsets()))
+        st.close()
+    eng.set_option("lm_cluster", 0)
+    assert out[0][2] == out[1][2] == [ctx + steps] * B
+    for (o0, l0), (o1, l1) in zip(out[0][0], out[1][0]):
+        assert np.isfinite(o1).all()
+        assert _maxerr(o0, o1) < ATOL and _maxerr(l0, l1) < 1e-3
+    for k0, k1 in zip(out[0][1], out[1][1]):
+        assert _maxerr(k0, k1) < ATOL
+
+
+def test_lm_cluster_mixed_positions_and_parked_rows():
+    """per-row offsets (rows prefilled to different lengths and copied into a batch; one row parked): the cluster
+    kernel reads every row's own position, like the per-layer path"""
+    eng = get_engine("en100m")
+    rng = np.random.default_rng(23)
+    lens = [7, 40, 19, 33, 12]
+    res = {}
+    for opt in (0, 1):
+        eng.set_option("lm_cluster", opt)
+        big = eng.new_lm_state(len(lens), 64)
+        r2 = np.random.default_rng(5)
+        for b, T in enumerate(lens):
+            one = eng.new_lm_state(1, 64)
+            eng.lm_prefill(one, dev((r2.standard_normal((1, T, eng.D)) * 0.3).astype(np.float32)))
+            big.copy_row_from(b, one)
+            eng.sync()
+            one.close()
+        big.set_row_active(3, False)
+        outs = []
+        for _ in range(4):
+            o, lg, _ = eng.lm_decode_step(big, None, None, 1, -4.0)
+            outs.append(o.cpu().numpy())
+        res[opt] = (outs, list(big.offsets()))
+        big.close()
+    eng.set_option("lm_cluster", 0)
+    assert res[0][1] == res[1][1] == [l + 4 if b != 3 else 0 for b, l in enumerate(lens)]
+    for a, b in zip(res[0][0], res[1][0]):
+        keep = [0, 1, 2, 4]
+        assert _maxerr(a[keep], b[keep]) < ATOL
+
+
+def test_lm_cluster_deterministic_under_load_and_two_states():
+    """bit-equal trajectories with a busy second stream, and two states stepped from two threads at once (their
+    cooperative launches are chained on the GPU, never starving each other)"""
+    eng = get_engine("en100m")
+    eng.set_option("lm_cluster", 1)
+    side = torch.cuda.Stream()
+    big = torch.randn(64 * 1024 * 1024, device="cuda:0")
+    mats = torch.randn(2048, 2048, device="cuda:0")
+    k = [0]
+
+    def busy():
+        k[0] += 1
+        with torch.cuda.stream(side):
+            if k[0] % 3 == 0:
+                big.mul_(1.0000001)
+            elif k[0] % 3 == 1:
+                torch.mm(mats, mats)
+
+    a, _ = _trajectory(eng, 64, 60, 1, 5, busy)
+    b, _ = _trajectory(eng, 64, 60, 1, 5, None)
+    side.synchronize()
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+    res = {}
+    ts = [threading.Thread(target=lambda: res.__setitem__(0, _trajectory(eng, 64, 60, 1, 5)[0])),
+          threading.Thread(target=lambda: res.__setitem__(1, _trajectory(eng, 48, 60, 1, 9)[0]))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert np.array_equal(res[0], a)
+    assert np.array_equal(res[1], _trajectory(eng, 48, 60, 1, 9)[0])
+    eng.set_option("lm_cluster", 0)

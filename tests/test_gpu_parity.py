@@ -258,7 +258,7 @@ def _run_pipeline_mode(eng, mode, B, Tp, ns, emb, ref):
         for i in range(ns + 1):
             f = pipe.step() if i < ns else pipe.flush()
             if f is not None:
-                pipe.ev[f & 1].synchronize()
+                pipe.done_event(f).synchronize()
                 got[f] = pipe.pcm_of(f).numpy().copy()
         assert sorted(got) == list(range(ns))
         for i in range(ns):

@@ -23,7 +23,7 @@ def pre():
 print("copy + text prefill(32) %.3f ms" % t(pre))
 print("pipe.restart            %.3f ms" % t(lambda: job.pipe.restart()))
 def first():
-    job.start_utterances(); job.pipe.step(); f = job.pipe.flush(); job.pipe.ev[f & 1].synchronize()
+    job.start_utterances(); job.pipe.step(); f = job.pipe.flush(); job.pipe.done_event(f).synchronize()
 print("whole first chunk       %.3f ms" % t(first))
 def steps():
     job.pipe.step()
