@@ -360,10 +360,41 @@ def cpu_baseline(args, cfg, W):
     return out
 
 
+def dryrun(args):
+    """`PTTS_BENCH_DRYRUN=1`: the multi-rank plumbing of this file WITHOUT a GPU (tests/test_host_cpu.py, world_size 2
+    over gloo): rendezvous, barriers, whole-job aggregation (sum of units over ranks / max wall over ranks), per-rank
+    values, ONE JSON line from rank 0.  Every rank pretends a wall time of 0.1 s x (rank + 1)."""
+    import torch
+
+    from pocket_tts_amd import parallel
+
+    rank, local, world = parallel.env_ranks()
+    dist = parallel.init_distributed("gloo")
+    if dist is not None:
+        dist.barrier()
+    wall_rank = 0.1 * (rank + 1)
+    audio_rank = args.batch * args.steps * FRAME_S
+    rate, wall = parallel.job_throughput(audio_rank, wall_rank, dist)
+    per_rank = [audio_rank / wall_rank]
+    if dist is not None:
+        t = torch.zeros(world, dtype=torch.float64)
+        t[rank] = per_rank[0]
+        dist.all_reduce(t)
+        per_rank = [float(v) for v in t.tolist()]
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "dryrun", "value": rate, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": wall * 1e3 / args.steps, "per_rank_xrt": per_rank, "scaling": "weak"}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    if os.environ.get("PTTS_BENCH_DRYRUN"):
+        return dryrun(args)
     import numpy as np
     import torch
 

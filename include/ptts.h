@@ -15,8 +15,10 @@
  * enqueue work on an engine serialise on that engine's mutex, so two threads MAY share one engine (e.g. a batching
  * scheduler thread and a request thread); device-side ordering between their calls is the caller's business
  * (streams / events).  A state or graph handle is not re-entrant: one thread per ptts_lm_state / ptts_mimi_state /
- * ptts_graph at a time.  At most ~8 decode steps of different states of one GPU should be in flight at once: the
- * single-launch flow MLP (ptts_set_option "flow_cluster") needs all its workgroups resident together.
+ * ptts_graph at a time.  Decode steps contain cooperative kernels (the single-launch flow MLP: all its workgroups must
+ * be resident together): the library chains such steps per DEVICE with an event (GPU-side order, no host wait), so
+ * steps of different states queued on different streams are safe and run one after the other on the GPU.  The one
+ * process-wide object is that per-device event (with its mutex).
  */
 #ifndef PTTS_H_
 #define PTTS_H_

@@ -2357,7 +2357,7 @@ extern "C" int ptts_graph_launch(ptts_graph *g, void *stream) {
       if (g->lm->h_off[b] + 1 > g->lm->cap) return fail(-5, "decode: KV cache capacity exceeded");
   }
   {
-    CoopGuard guard(e->device, S(e, stream), g->lm != nullptr);
+    CoopGuard guard(e->device, S(e, stream), g->lm != nullptr && (e->opt_lm_cluster || e->opt_flow_cluster));
     HIPCHK(hipGraphLaunch(g->exec, S(e, stream)));
   }
   if (g->lm) for (int b = 0; b < g->lm->B; ++b) g->lm->h_off[b] += g->lm->h_active[b];

@@ -78,7 +78,9 @@ template <int RT, int KPW>
 __global__ __launch_bounds__(FLOW_THREADS) void flow_cluster_kernel(FlowArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int FDF = a.FDF, LF = a.LF;
-  const int cl = blockIdx.x % a.NCL, j = blockIdx.x / a.NCL;  // resident cluster, column tile
+  // workgroups with the same column tile j (they stream the SAME weight tiles) sit 8 apart in blockIdx, i.e. on one XCD
+  // under round-robin placement (speed only): the clusters' weight re-reads are then L2 hits instead of fabric reads
+  const int cl = blockIdx.x / a.FDF, j = blockIdx.x % a.FDF;  // resident cluster, column tile
   const bool coord = wave == FLOW_WORKERS;
   const int PPS = 2 * a.depth + 2, NPH = a.steps * PPS;
   __shared__ f32x4 red[FLOW_WORKERS][RT][64];

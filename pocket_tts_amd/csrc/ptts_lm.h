@@ -49,7 +49,7 @@ __global__ __launch_bounds__(FLOW_THREADS) void lm_cluster_kernel(LmArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: k ranges and buffer offsets stay scalar
   const int DF = a.DF, FFF = a.FFF, H = a.H;
-  const int cl = blockIdx.x % a.NCL, j = blockIdx.x / a.NCL;  // resident cluster, workgroup in the cluster (0 .. DF-1)
+  const int cl = blockIdx.x / a.DF, j = blockIdx.x % a.DF;  // resident cluster, workgroup in the cluster (same j = same XCD)
   const int hd = j >> 2, qd = j & 3;                          // phase A / B role: head, 16-column quarter of the head
   const bool coord = wave == FLOW_WORKERS;
   const int NFF = FFF / DF;  // linear1 column tiles per workgroup (host: <= 4)

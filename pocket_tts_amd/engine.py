@@ -490,7 +490,8 @@ class StepPipeline:
     """
 
     def __init__(self, eng: Engine, lm_state: LMState, mimi_state: MimiState, noise=None, lsd_steps: int = 1,
-                 eos_threshold: float = -4.0, mode: str | None = None, pcm_i16: bool = False):
+                 eos_threshold: float = -4.0, mode: str | None = None, pcm_i16: bool = False,
+                 lm_stream: torch.cuda.Stream | None = None):
         self.eng, self.st, self.ms = eng, lm_state, mimi_state
         B, dev = lm_state.batch, eng.device
         self.mode = mode or ("hostsync" if B <= 8 else "events")
@@ -504,6 +505,7 @@ class StepPipeline:
         self.pcm = [torch.zeros(B, eng.frame_samples).pin_memory() for _ in range(nb)]
         self.ev = [torch.cuda.Event() for _ in range(nb)]    # codec frame (f % nb) complete -> pcm_of(f) valid
         self.ev_lm = [torch.cuda.Event() for _ in range(nb)]  # FlowLM step (t % nb) complete -> flag valid
+        self.s1 = lm_stream or eng.stream  # FlowLM stream (several pipelines of one engine may use their own)
         self.s2 = torch.cuda.Stream(device=dev, priority=int(os.environ.get("PTTS_PRIO_CODEC", "0")))
         eng.sync()
         torch.cuda.synchronize(dev)
@@ -568,18 +570,18 @@ class StepPipeline:
             else:
                 eng.graph_launch(self.g_first[p])
         elif self.mode == "events":
-            eng.stream.wait_event(self.ev[p])          # codec frame t-2 done: lat[p] / pcm[p] are free
-            eng.graph_launch(self.g_first[p])          # FlowLM step t -> lat[p]
-            self.ev_lm[p].record(eng.stream)
+            self.s1.wait_event(self.ev[p])             # codec frame t-nb done: lat[p] / pcm[p] are free
+            eng.graph_launch(self.g_first[p], self.s1)  # FlowLM step t -> lat[p]
+            self.ev_lm[p].record(self.s1)
             self.s2.wait_event(self.ev_lm[p])
             eng.graph_launch(self.g_last[p], self.s2)  # codec frame t -> pcm[p] (overlaps FlowLM step t+1)
             self.ev[p].record(self.s2)
             self.decoded += 1
             done = self.t
         else:
-            eng.stream.wait_event(self.ev[p])  # frame t-2 decoded: lat[p] / pcm[p] may be reused (long done)
-            eng.graph_launch(self.g_first[p])
-            self.ev_lm[p].record(eng.stream)
+            self.s1.wait_event(self.ev[p])  # frame t-2 decoded: lat[p] / pcm[p] may be reused (long done)
+            eng.graph_launch(self.g_first[p], self.s1)
+            self.ev_lm[p].record(self.s1)
             if self.decoded < self.t:
                 done = self._decode_pending()
         self.t += 1
@@ -589,9 +591,9 @@ class StepPipeline:
     def lm_step_async(self) -> int:
         """launch FlowLM step t on stream 1; returns t"""
         p = self.t % self.nb
-        self.eng.stream.wait_event(self.ev[p])  # frame t-2 decoded: lat[p] may be overwritten
-        self.eng.graph_launch(self.g_first[p])
-        self.ev_lm[p].record(self.eng.stream)
+        self.s1.wait_event(self.ev[p])  # frame t-2 decoded: lat[p] may be overwritten
+        self.eng.graph_launch(self.g_first[p], self.s1)
+        self.ev_lm[p].record(self.s1)
         self.t += 1
         return self.t - 1
 
@@ -631,6 +633,7 @@ class StepPipeline:
         return self.pcm16[frame % self.nb]
 
     def sync(self):
+        self.s1.synchronize()
         self.eng.stream.synchronize()
         self.s2.synchronize()
 

@@ -133,6 +133,22 @@ def test_bench_presets_and_rank_spawning():
                            capture_output=True, text=True, timeout=300)
         assert r.returncode != 0
         assert "rank 0 exited" in r.stderr and "rank 1 exited" in r.stderr
+    # the rank plumbing end to end on CPU (world_size 2, gloo): spawned ranks rendezvous on 127.0.0.1, the value is the
+    # sum of the ranks' audio over the MAX of their wall times, rank 0 alone prints the line
+    import json
+    import os
+
+    env = dict(os.environ, PTTS_BENCH_DRYRUN="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, bench.__file__, "--gpus", "2", "--steps", "10", "--warmup", "0", "--batch", "5"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    audio = 5 * 10 * 0.08
+    assert d["n_gpus"] == 2 and abs(d["value"] - 2 * audio / 0.2) < 1e-6
+    assert [round(v, 6) for v in d["per_rank_xrt"]] == [round(audio / 0.1, 6), round(audio / 0.2, 6)]
 
 
 def test_drop_in_package_name():

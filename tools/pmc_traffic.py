@@ -1,6 +1,9 @@
 """rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (separate runs) -> profiles/*_pmc_traffic.json.
 
-    python tools/pmc_traffic.py <dir of the FETCH_SIZE run> <dir of the WRITE_SIZE run> <out.json> ["note"]
+    python tools/pmc_traffic.py <dir of the FETCH_SIZE run> <dir of the WRITE_SIZE run> <out.json> ["note"] [tune_table_id]
+
+`tune_table_id` (bench.py prints it) stamps the file with the tile table the kernels were chosen from: bench.py only
+replays these numbers into `roofline.traffic` when its own run uses the same table.
 
 Per kernel (named as bench.py's profiler names them): launches, HBM-side read / write bytes per launch and their sum.
 Units and the gfx950 correction follow MI355X_MICROARCH.md: both counters are in KiB; FETCH_SIZE reports exactly
@@ -19,6 +22,9 @@ def norm(name):
     m = re.search(r"gemm_lds_kernel<(\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>", name)
     if m:
         return "gemm_lds<%s,%s,%s>%s" % (m.group(1), m.group(2), m.group(3), PRE.get(int(m.group(4)), ""))
+    m = re.search(r"gemm_h_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>", name)
+    if m:
+        return "gemm_h<%s,%s,%s,%s>%s" % (*m.groups()[:4], "+ln" if m.group(5) == "3" else "")
     m = re.match(r"(?:void )?(\w+?)(?:_kernel)?[<(]", name)
     return m.group(1) if m else name
 
@@ -30,7 +36,7 @@ def collect(d, counter):
             if r["Counter_Name"] != counter:
                 continue
             name = norm(r["Kernel_Name"])
-            if name.startswith(("gemm", "attn")) and not name.startswith("attn_combine"):
+            if name.startswith(("gemm", "attn", "flow_cluster", "lm_cluster")) and not name.startswith("attn_combine"):
                 name += "@" + r["Grid_Size"]  # as bench.py's profiler labels them: one label = one grid = one shape class
             a = acc[name]
             a[0] += 1
@@ -41,6 +47,7 @@ def collect(d, counter):
 def main():
     fd, wd, out = sys.argv[1:4]
     note = sys.argv[4] if len(sys.argv) > 4 else ""
+    table_id = sys.argv[5] if len(sys.argv) > 5 else None
     F, W = collect(fd, "FETCH_SIZE"), collect(wd, "WRITE_SIZE")
     ks = {}
     for k in sorted(set(F) | set(W)):
@@ -48,7 +55,7 @@ def main():
         rd = 2.0 * 1024.0 * F[k][1] / max(F[k][0], 1)
         wr = 1024.0 * W[k][1] / max(W[k][0], 1)
         ks[k] = dict(launches=n, hbm_read_bytes_per_launch=rd, hbm_write_bytes_per_launch=wr, traffic_bytes_per_launch=rd + wr)
-    json.dump(dict(note=note, kernels=ks), open(out, "w"), indent=1)
+    json.dump(dict(note=note, tune_table_id=table_id, kernels=ks), open(out, "w"), indent=1)
     for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"] * kv[1]["launches"])[:25]:
         print(f"{k:34s} n={v['launches']:5d}  read {v['hbm_read_bytes_per_launch']/1e6:9.2f} MB  write {v['hbm_write_bytes_per_launch']/1e6:8.2f} MB")
 
