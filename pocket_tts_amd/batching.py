@@ -168,10 +168,10 @@ class ContinuousBatcher:
             b = free[0]
             one = None
             try:
-                t_voice = _state_current_end(job.voice)
+                voice_st, t_voice = self.model._voice_lm_state(job.voice)  # device-resident voice, no host sync
                 Tt = job.tokens.shape[1]
                 one = eng.new_lm_state(1, t_voice + Tt)
-                one.copy_from(self.model._voice_lm_state(job.voice, t_voice))  # device-resident voice, no host sync
+                one.copy_from(voice_st)
                 eng.lm_prefill(one, eng.embed_text(job.tokens))
                 self.st.copy_row_from(b, one)       # KV rows, position, BOS as the pending input, row active
                 eng.sync()

@@ -294,28 +294,31 @@ class TTSModel:
             if n_emit[b] is None or frame < n_emit[b]:
                 chunks[b].append(pcm[b].clone())
 
-    def _voice_lm_state(self, model_state: dict, t_voice: int):
+    def _voice_lm_state(self, model_state: dict, t_voice: int | None = None):
         """Device-resident engine-layout copy of a voice state dict, built on first use and reused while the dict's
-        tensors are unchanged (same storage, same in-place version, same offset); at most 8 voices stay resident."""
+        tensors are unchanged (same storage, same in-place version); at most 8 voices stay resident.  Returns
+        `(LMState, t_voice)`; on a hit nothing touches the device (the reference reads `offset` with `.item()` on every
+        call, tts_model.py:412-414: a device sync when the state lives on the GPU)."""
         with self._voice_lock:
-            return self._voice_lm_state_locked(model_state, t_voice)
-
-    def _voice_lm_state_locked(self, model_state: dict, t_voice: int):
-        eng = self.engine
-        sig = tuple((model_state[_layer_key(i)]["cache"].data_ptr(), model_state[_layer_key(i)]["cache"]._version)
-                    for i in range(eng.L)) + (t_voice,)
-        hit = self._voice_cache.get(id(model_state))
-        if hit is not None and hit[0] == sig:
-            return hit[1]
-        if hit is not None:
-            hit[1].close()
-        while len(self._voice_cache) >= 8:
-            self._voice_cache.pop(next(iter(self._voice_cache)))[1].close()
-        vst = eng.new_lm_state(1, max(t_voice, 1))
-        _import_lm_state(eng, vst, model_state, t_voice)
-        # the entry keeps the source tensors alive, so a recycled id() / data_ptr() can never alias a cached voice
-        self._voice_cache[id(model_state)] = (sig, vst, [model_state[_layer_key(i)]["cache"] for i in range(eng.L)])
-        return vst
+            eng = self.engine
+            sig = tuple((model_state[_layer_key(i)]["cache"].data_ptr(), model_state[_layer_key(i)]["cache"]._version,
+                         model_state[_layer_key(i)]["offset"].data_ptr(), model_state[_layer_key(i)]["offset"]._version)
+                        for i in range(eng.L))
+            hit = self._voice_cache.get(id(model_state))
+            if hit is not None and hit[0] == sig:
+                return hit[1], hit[3]
+            if hit is not None:
+                hit[1].close()
+            while len(self._voice_cache) >= 8:
+                self._voice_cache.pop(next(iter(self._voice_cache)))[1].close()
+            if t_voice is None:
+                t_voice = _state_current_end(model_state)
+            vst = eng.new_lm_state(1, max(t_voice, 1))
+            _import_lm_state(eng, vst, model_state, t_voice)
+            # the entry keeps the source tensors alive, so a recycled id() / data_ptr() can never alias a cached voice
+            keep = [model_state[_layer_key(i)][k] for i in range(eng.L) for k in ("cache", "offset")]
+            self._voice_cache[id(model_state)] = (sig, vst, keep, t_voice)
+            return vst, t_voice
 
     def _draw_noise(self, out: torch.Tensor):
         """Same draws as the reference CPU path (flow_lm.py:131-137): torch's global CPU generator."""
@@ -330,7 +333,7 @@ class TTSModel:
         tokens = torch.tensor(self.tokenizer.encode(text), dtype=torch.long)[None, :]
         Tt = tokens.shape[1]
         max_gen_len = estimate_max_gen_len(Tt, self.config.mimi.frame_rate)
-        t_voice = _state_current_end(model_state)
+        voice_st, t_voice = self._voice_lm_state(model_state)  # no device sync when the voice is already resident
         use_noise = self.temp > 0
         t_start = time.monotonic()
         # states, scratch and captured graphs are reused across chunks and calls (capacity rounded up)
@@ -347,11 +350,13 @@ class TTSModel:
             ctx = dict(st=st, ms=ms, noise_dev=noise_dev, pipe=pipe, noise_host=torch.zeros(1, eng.ldim).pin_memory())
         st, ms, noise_dev, pipe = ctx["st"], ctx["ms"], ctx["noise_dev"], ctx["pipe"]
         noise_host = ctx["noise_host"]
-        pipe.restart()
         # per-chunk clone of the voice state (replaces deepcopy + _expand_kv_cache, tts_model.py:637-638,390-421): the
-        # voice's KV lives on the device in the engine's layout, one row-copy kernel clones it, nothing synchronises
-        st.copy_from(self._voice_lm_state(model_state, t_voice))
+        # voice's KV lives on the device in the engine's layout, one row-copy kernel clones it, nothing synchronises.
+        # Clone + prefill are queued BEFORE the codec reset: the GPU starts on them while the host issues the rest.
+        pipe.flush()
+        st.copy_from(voice_st)
         eng.lm_prefill(st, eng.embed_text(tokens))            # text prefill (tts_model.py:722-725)
+        pipe.restart()
         if use_noise:
             # the reference's text prefill runs the whole forward, including one (discarded) noise draw
             # (tts_model.py:722-725 -> flow_lm.py:131-137): consume it to stay on the same generator stream
@@ -367,6 +372,13 @@ class TTSModel:
                 return pipe.pcm_of(frame)[0].clone()
 
             for step in range(max_gen_len):
+                if yielded == 0 and emitted == 1:
+                    # first chunk: hand it over before the next FlowLM step is queued beside its codec frame (the two
+                    # would share the chip and the chunk would arrive later); from here on step t+1 overlaps frame t
+                    chunk = pop(0)
+                    yielded = 1
+                    total += chunk.shape[0]
+                    yield chunk
                 if use_noise:
                     self._draw_noise(noise_host)
                     with torch.cuda.stream(eng.stream):
