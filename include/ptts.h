@@ -176,6 +176,8 @@ void ptts_graph_destroy(ptts_graph *g);
  * heuristic.  Results are numerically equivalent up to fp32 summation order.  Synchronises.
  * ptts_tune_log: one text line per tuned shape (valid until the next tune/clear). */
 int ptts_tune(ptts_engine *e, int32_t batch, void *stream);
+/* the same for the prefill GEMM shapes of `batch` sequences x `t` positions (text prefill of a chunk: first-chunk path) */
+int ptts_tune_prefill(ptts_engine *e, int32_t batch, int32_t t, void *stream);
 const char *ptts_tune_log(ptts_engine *e);
 void ptts_tune_clear(ptts_engine *e);
 /* The tuned table as text (one line per GEMM shape) so that a deployment tunes once: export after ptts_tune,

@@ -2101,6 +2101,43 @@ extern "C" int ptts_tune(ptts_engine *e, int32_t B, void *stream) {
   return rc;
 }
 
+// Same for the prefill GEMM shapes of `batch` sequences x `t` positions (first-chunk path: text prefill of a chunk).
+extern "C" int ptts_tune_prefill(ptts_engine *e, int32_t B, int32_t T, void *stream) {
+  if (!e || B < 1 || T < 1) return fail(-1, "bad argument");
+  ENGINE_LOCK(e);
+  HIPCHK(hipSetDevice(e->device));
+  hipStream_t st = S(e, stream);
+  Tuner &t = *e->tuner;
+  ptts_lm_state *ls = nullptr;
+  float *emb = nullptr;
+  int rc = ptts_lm_state_create(e, B, T + 16, &ls);
+  t.flush_bytes = (size_t)320 << 20;
+  if (rc == 0 && hipMalloc((void **)&emb, (size_t)B * T * e->cfg.d_model * 4) != hipSuccess) { (void)hipGetLastError(); rc = fail(-2, "hipMalloc"); }
+  if (rc == 0) {
+    (void)hipMemsetAsync(emb, 0, (size_t)B * T * e->cfg.d_model * 4, st);
+    if (hipMalloc(&t.flush, t.flush_bytes) != hipSuccess) { t.flush = nullptr; (void)hipGetLastError(); }
+    else (void)hipMemsetAsync(t.flush, 0, t.flush_bytes, st);
+  }
+  if (rc == 0 && (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess)) rc = fail(-2, "hipEventCreate");
+  if (rc == 0) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const bool prof = e->prof.on;
+    e->prof.on = false;
+    t.active = true;
+    rc = ptts_lm_prefill(e, ls, emb, T, st);
+    t.active = false;
+    e->prof.on = prof;
+    if (hipStreamSynchronize(st) != hipSuccess && rc == 0) rc = fail(-2, "tune_prefill: stream error");
+  }
+  if (t.e0) hipEventDestroy(t.e0);
+  if (t.e1) hipEventDestroy(t.e1);
+  t.e0 = t.e1 = nullptr;
+  if (t.flush) hipFree(t.flush);
+  t.flush = nullptr;
+  if (emb) hipFree(emb);
+  if (ls) ptts_lm_state_destroy(ls);
+  return rc;
+}
 extern "C" int ptts_tune_version(void) { return kTuneVersion; }
 extern "C" const char *ptts_tune_log(ptts_engine *e) { return e ? e->tuner->log.c_str() : ""; }
 

@@ -304,6 +304,11 @@ class Engine:
         before = self._tune_table()
         self._pre()
         _lib.check(self.lib.ptts_tune(self.handle, int(batch), self._sp))
+        if batch == 1:
+            # streaming path: the text prefill of a chunk sits on the first-chunk latency; its GEMM shapes depend on
+            # ceil(tokens / 16) only (chunks hold <= 50 tokens + padding)
+            for t in (16, 32, 48, 64):
+                _lib.check(self.lib.ptts_tune_prefill(self.handle, 1, t, self._sp))
         self._tuned.add(batch)
         after = self._tune_table()
         new = [ln for ln in after if ln not in before]
