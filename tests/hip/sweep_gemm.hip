@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tests/hip/sweep_gemm tests/hip/sweep_gemm.hip && tests/hip/sweep_gemm
 // Prints one line per (shape, config) with the time of a back-to-back launch, best config first.
 #include "../../pocket_tts_amd/csrc/ptts_kernels.h"
+#include "exp_lds32.h"
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -56,8 +57,33 @@ static void run_lds(std::vector<Res> &out, int M, int N, int K, int ntaps, int T
   char nm[64]; snprintf(nm, sizeof nm, "LDS<%d,%d,%d>", BMT, BNT, KC);
   out.push_back({nm, us, (int)grid.x, (int)grid.y});
 }
+template <int WM, int WN, int KC>
+static void run_lds32(std::vector<Res> &out, int M, int N, int K, int ntaps, int T) {
+  constexpr int BMT = 4 * WM, BNT = 4 * WN;
+  int MT = cdiv(M, 16), NT = cdiv(N, 16), CF = K / 16, KF = CF * ntaps;
+  if (KF % KC || BMT > 2 * MT || BNT > 2 * NT) return;
+  size_t wsz = (size_t)NT * KF * 256, xsz = (size_t)MT * CF * 256, ysz = (size_t)MT * NT * 256;
+  if ((wsz + 2 * xsz + ysz + 64) * 4 > ((size_t)3 << 30)) return;
+  GemmArgs a; memset(&a, 0, sizeof a);
+  a.W = g_buf; a.X = g_buf + wsz; a.Y = g_buf + wsz + 2 * xsz; a.Xdstride = ntaps > 1 ? xsz : 0;
+  a.par = ntaps > 1 ? (int *)(g_buf + wsz + 2 * xsz + ysz) : nullptr;
+  a.NT = NT; a.KF = KF; a.CF = CF; a.ntaps = ntaps; a.XF = CF; a.MT = MT; a.M = M; a.T = T; a.epi = EPI_STORE; a.YF = NT; a.xstride = 1; a.halo = ntaps - 1;
+  dim3 grid(cdiv(NT, BNT), cdiv(MT, BMT));
+  auto launch = [&] { gemm_lds32_kernel<WM, WN, KC><<<grid, 256, 0, g_st>>>(a); };
+  for (int i = 0; i < 3; ++i) launch();
+  hipStreamSynchronize(g_st);
+  const int R = 20;
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < R; ++i) launch();
+  hipStreamSynchronize(g_st);
+  double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / R;
+  char nm[64]; snprintf(nm, sizeof nm, "L32<%d,%d,%d>", WM, WN, KC);
+  out.push_back({nm, us, (int)grid.x, (int)grid.y});
+}
 static void sweep(const char *name, int M, int N, int K, int ntaps, int T) {
   std::vector<Res> r;
+  run_lds32<1, 1, 2>(r, M, N, K, ntaps, T); run_lds32<2, 1, 2>(r, M, N, K, ntaps, T); run_lds32<1, 2, 2>(r, M, N, K, ntaps, T);
+  run_lds32<2, 2, 2>(r, M, N, K, ntaps, T); run_lds32<2, 2, 4>(r, M, N, K, ntaps, T); run_lds32<1, 1, 4>(r, M, N, K, ntaps, T);
   run_lds<8, 4, 2>(r, M, N, K, ntaps, T); run_lds<8, 8, 2>(r, M, N, K, ntaps, T); run_lds<4, 4, 2>(r, M, N, K, ntaps, T);
   run_lds<8, 4, 4>(r, M, N, K, ntaps, T); run_lds<4, 4, 4>(r, M, N, K, ntaps, T); run_lds<8, 2, 2>(r, M, N, K, ntaps, T);
   run_lds<4, 2, 2>(r, M, N, K, ntaps, T); run_lds<4, 8, 2>(r, M, N, K, ntaps, T);
@@ -70,13 +96,13 @@ static void sweep(const char *name, int M, int N, int K, int ntaps, int T) {
   std::sort(r.begin(), r.end(), [](const Res &a, const Res &b) { return a.us < b.us; });
   double fl = 2.0 * M * N * (double)K * ntaps;
   printf("%-28s M=%-6d N=%-5d K=%dx%-4d |", name, M, N, ntaps, K);
-  for (size_t i = 0; i < r.size() && i < 5; ++i) printf(" %s %.1fus(%dx%d)", r[i].cfg.c_str(), r[i].us, r[i].gx, r[i].gy);
+  for (size_t i = 0; i < r.size() && i < 7; ++i) printf(" %s %.1fus(%dx%d)", r[i].cfg.c_str(), r[i].us, r[i].gx, r[i].gy);
   printf(" | best %.1f TF\n", fl / r[0].us * 1e-6);
 }
 int main() {
   hipStreamCreate(&g_st);
   hipMalloc(&g_buf, (size_t)3 << 30); hipMemset(g_buf, 0, (size_t)3 << 30);
-  const int Bs[] = {16, 64};
+  const int Bs[] = {64};
   for (int B : Bs) {
     printf("---- batch %d\n", B);
     sweep("lm.qkv", B, 3072, 1024, 1, 16); sweep("lm.out", B, 1024, 1024, 1, 16);

@@ -1,6 +1,7 @@
 // Native unit test of the device kernels against plain C++ loops (runs on the GPU box):
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 -o tests/hip/test_kernels tests/hip/test_kernels.hip && tests/hip/test_kernels
 #include "../../pocket_tts_amd/csrc/ptts_kernels.h"
+#include "exp_lds32.h"
 
 #include <cmath>
 #include <cstdio>
@@ -53,7 +54,12 @@ static void test_gemm(int M, int N, int K, int cfg) {
   GemmArgs a; memset(&a, 0, sizeof(a));
   a.W = wp; a.bias = bp; a.NT = NT; a.KF = KF; a.CF = KF; a.ntaps = 1; a.X = xfm; a.XF = KF; a.MT = MT; a.M = M; a.T = 16;
   a.epi = EPI_STORE; a.Y = yfm; a.YF = NT;
-  if (cfg >= 100) {
+  if (cfg == 102 || cfg == 103) {  // 32x32x2 MFMA tiles: workgroup = 64 x 64 (cfg 102) or 128 x 128 (cfg 103)
+    const int b16 = cfg == 102 ? 4 : 8;
+    dim3 grid(cdiv(a.NT, b16), cdiv(a.MT, b16));
+    if (cfg == 102) gemm_lds32_kernel<1, 1, 2><<<grid, 256>>>(a); else gemm_lds32_kernel<2, 2, 2><<<grid, 256>>>(a);
+    CK(hipDeviceSynchronize());
+  } else if (cfg >= 100) {
     dim3 grid(cdiv(a.NT, cfg == 100 ? 4 : 8), cdiv(a.MT, 8));
     if (cfg == 100) gemm_lds_kernel<8, 4, 2, PRE_NONE><<<grid, 256>>>(a); else gemm_lds_kernel<8, 8, 2, PRE_NONE><<<grid, 256>>>(a);
     CK(hipDeviceSynchronize());
@@ -100,7 +106,10 @@ static void test_conv(int B, int T, int C, int N, int ntaps, int cfg) {
   GemmArgs a; memset(&a, 0, sizeof(a));
   a.W = wp; a.bias = bp; a.NT = NT; a.KF = KF; a.CF = CF; a.ntaps = ntaps; a.X = xfm; a.Xdstride = xs; a.XF = CF; a.MT = MT; a.M = M; a.T = T; a.par = par; a.xstride = 1; a.halo = ntaps - 1;
   a.epi = EPI_STORE; a.Y = yfm; a.YF = NT;
-  if (cfg >= 100) {
+  if (cfg == 102) {
+    dim3 grid(cdiv(a.NT, 4), cdiv(a.MT, 4));
+    gemm_lds32_kernel<1, 1, 2><<<grid, 256>>>(a);
+  } else if (cfg >= 100) {
     dim3 grid(cdiv(a.NT, 4), cdiv(a.MT, cfg == 100 ? 8 : 4));
     if (cfg == 100) gemm_lds_kernel<8, 4, 2, PRE_NONE><<<grid, 256>>>(a); else gemm_lds_kernel<4, 4, 2, PRE_NONE><<<grid, 256>>>(a);
     CK(hipDeviceSynchronize());
@@ -215,11 +224,13 @@ int main() {
   test_gemm(100, 1, 64, 5);
   test_gemm(1, 384, 4096, 0);
   test_gemm(200, 130, 128, 100); test_gemm(300, 200, 512, 101); test_gemm(1024, 64, 64, 100);
+  test_gemm(200, 130, 128, 102); test_gemm(300, 200, 512, 103); test_gemm(1024, 64, 64, 102); test_gemm(40, 48, 32, 102);
   test_conv(2, 16, 32, 48, 7, 0);
   test_conv(3, 32, 64, 32, 3, 2);
   test_conv(5, 48, 32, 70, 2, 3);
   test_conv(4, 96, 16, 1, 3, 5);
   test_conv(5, 48, 32, 70, 2, 100); test_conv(3, 32, 64, 96, 3, 101); test_conv(9, 16, 32, 64, 7, 100);
+  test_conv(5, 48, 32, 70, 2, 102); test_conv(9, 16, 32, 64, 7, 102);
   test_gemm_lnfold(3, 48, 128, 0); test_gemm_lnfold(50, 96, 1024, 2); test_gemm_lnfold(200, 130, 512, 3);
   test_gemm_lnfold(130, 64, 1024, 7);
   test_attn(4, 1, 0, 0, 0, 1);
