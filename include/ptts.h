@@ -176,6 +176,9 @@ void ptts_graph_destroy(ptts_graph *g);
  * heuristic.  Results are numerically equivalent up to fp32 summation order.  Synchronises.
  * ptts_tune_log: one text line per tuned shape (valid until the next tune/clear). */
 int ptts_tune(ptts_engine *e, int32_t batch, void *stream);
+/* the same with the FlowLM step tuned on `lm_stream` and the codec frame on `codec_stream`: with CU-masked streams
+ * (ptts_stream_create_masked) each stage gets the tiles that are fastest on its own share of the chip */
+int ptts_tune_streams(ptts_engine *e, int32_t batch, void *lm_stream, void *codec_stream);
 /* the same for the prefill GEMM shapes of `batch` sequences x `t` positions (text prefill of a chunk: first-chunk path) */
 int ptts_tune_prefill(ptts_engine *e, int32_t batch, int32_t t, void *stream);
 const char *ptts_tune_log(ptts_engine *e);
@@ -196,6 +199,8 @@ int ptts_tune_import(ptts_engine *e, const char *text);
  *                                           DESIGN.md section 3), 0 = five launches per layer
  *   "k_rotate"      [PTTS_K_ROTATE, 0]      1 = K-split GEMM workgroups start their K loop at a column-block dependent
  *                                           chunk (spreads the re-reads of the shared activation rows over L2 channels)
+ *   "flow_max_cus"  [-, 128]                resident workgroups of the cooperative flow launch (8..256): at most the number
+ *                                           of CUs its stream may use (a CU-masked FlowLM stream needs it lowered)
  * Applies to steps enqueued / graphs captured after the call.  Returns -1 for an unknown key. */
 int ptts_set_option(ptts_engine *e, const char *key, int32_t value);
 /* 1 after a cooperative kernel of this state gave up waiting for a peer workgroup (its outputs are then invalid);

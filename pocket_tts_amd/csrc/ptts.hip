@@ -125,6 +125,7 @@ struct ptts_engine {
   int opt_lm_cluster = 0;  // measured slower than five launches per layer: kept as an experiment
   LmLayerP *lm_table = nullptr;  // device table of the FlowLM layers for lm_cluster_kernel (null: not eligible)
   int opt_k_rotate = 0;
+  int opt_flow_max_cus = 128;  // resident workgroups of the single-launch flow MLP (<= the CUs its stream may use)
   std::recursive_mutex mu;  // entry points that enqueue work or touch tuner / profiler / LSD tables hold it
   int quant_flags = 0;
 };
@@ -696,13 +697,31 @@ static int attn_wave_target() {
   static int t = [] { const char *v = getenv("PTTS_ATTN_WAVES"); return v ? atoi(v) : 1024; }();
   return t;
 }
+// waves per workgroup of attn_kernel (they split the workgroup's key tiles and merge in LDS, no combine launch).
+// Only for small launches: on the codec frame at batch 64 (512 (sequence, head) pairs, 17 key tiles) 4 waves x 1 split
+// is faster alone (18.2 us against 19.8 us + the combine launch, tests/hip/sweep_attn.hip) but SLOWER in the two-stream
+// pipeline (0.958 vs 0.947 ms per step, 2 waves 0.963 vs 0.955; tools/ab_attn_nw.sh): the extra resident waves delay
+// the FlowLM stream's kernels.  At batch 8 / 1 it saves 1.5 / 1.1 us per layer.
+static int attn_nw(int base) {
+  static const int forced = [] { const char *v = getenv("PTTS_ATTN_KERNEL_NW"); return v ? atoi(v) : 0; }();  // A/B knob
+  if (forced) return forced;
+  return base <= 128 ? 4 : (base <= 256 ? 2 : 1);
+}
 static int attn_splits(int base, int max_tiles) {
-  // one wave per (sequence, head, query block, split).  Keys are split only until ~1024 waves exist (measured at
-  // batch 64: 1024 -> 1.139 ms/step, 4096 -> 1.168, 8192 -> 1.211; more splits only add combine launches);
-  // a split never gets less than ~2 key tiles.  PTTS_ATTN_WAVES overrides the target for experiments.
-  int s = std::max(1, cdiv(attn_wave_target(), std::max(1, base)));
-  s = std::min(s, std::max(1, max_tiles / 2));
-  return std::max(1, std::min(s, max_tiles));
+  // `base` = (sequence, head, query block) triples.  Keys are split over workgroups only until ~1024 waves exist
+  // (measured at batch 64: 1024 -> 1.139 ms/step, 4096 -> 1.168, 8192 -> 1.211; more splits only add combine launches);
+  // a wave never gets less than ~1 key tile.  PTTS_ATTN_WAVES overrides the target for experiments.
+  const int nw = attn_nw(base);
+  const int tiles = cdiv(max_tiles, nw);
+  int s = std::max(1, cdiv(attn_wave_target(), std::max(1, base * nw)));
+  return std::max(1, std::min(s, tiles));
+}
+static void launch_attn(hipStream_t st, const AttnArgs &at, int BH) {
+  const dim3 grid(BH, at.QB, at.splits);
+  const int nw = attn_nw(BH * at.QB);
+  if (nw == 4) attn_kernel<4><<<grid, 256, 0, st>>>(at);
+  else if (nw == 2) attn_kernel<2><<<grid, 128, 0, st>>>(at);
+  else attn_kernel<1><<<grid, 64, 0, st>>>(at);
 }
 
 // One pre-LN transformer layer on M rows (reference mimi_transformer.py:39-54, transformer.py:135-158)
@@ -739,17 +758,19 @@ static void run_tr_layer(hipStream_t st, const TrLayer &T, const TrCtx &c) {
   SITE(s3.c_str());
   {
     // K and V rows of every attended key once per head + q in + o out
-    ProfScope ps(st, std::string(c.Tq == 1 ? "attn_decode" : "attn") + "@" + std::to_string((long)BH * c.QB * c.splits * 64 * (c.Tq == 1 ? decode_attn_waves(BH) : 1)), c.kv_keys * c.H * 64 * 4 * 2 + 8.0 * c.M * c.D, 4.0 * c.kv_keys * c.H * 64 * std::min(c.Tq, 16));
+    ProfScope ps(st, std::string(c.Tq == 1 ? "attn_decode" : "attn") + "@" + std::to_string((long)BH * c.QB * c.splits * 64 * (c.Tq == 1 ? decode_attn_waves(BH) : attn_nw(BH * c.QB))), c.kv_keys * c.H * 64 * 4 * 2 + 8.0 * c.M * c.D, 4.0 * c.kv_keys * c.H * 64 * std::min(c.Tq, 16));
     if (c.Tq == 1) {
       // one query: vector ALU + wave reductions.  The keys of a (sequence, head) are split over the nw waves of ONE
       // workgroup and merged in LDS, so small batches reach ~1024 waves without partial buffers or a combine launch
       const int nw = decode_attn_waves(BH);
-      if (nw >= 8) attn_decode_kernel<8><<<dim3(BH, 1, c.splits), 512, 0, st>>>(at);
-      else if (nw == 4) attn_decode_kernel<4><<<dim3(BH, 1, c.splits), 256, 0, st>>>(at);
-      else if (nw == 2) attn_decode_kernel<2><<<dim3(BH, 1, c.splits), 128, 0, st>>>(at);
+      // small batches (latency-bound): the row-state kernel with no cross-row traffic in its loop (6.0 vs 7.2 us per layer
+      // at batch 1, 221 keys); at >= 1024 (sequence, head) pairs both stream at the same rate and the first one stays
+      if (nw >= 8) attn_decode2_kernel<8, 3><<<dim3(BH, 1, c.splits), 512, 0, st>>>(at);
+      else if (nw == 4) attn_decode2_kernel<4, 3><<<dim3(BH, 1, c.splits), 256, 0, st>>>(at);
+      else if (nw == 2) attn_decode2_kernel<2, 3><<<dim3(BH, 1, c.splits), 128, 0, st>>>(at);
       else attn_decode_kernel<1><<<dim3(BH, 1, c.splits), 64, 0, st>>>(at);
     }
-    else attn_kernel<<<dim3(BH, c.QB, c.splits), 64, 0, st>>>(at);
+    else launch_attn(st, at, BH);
   }
   if (c.splits > 1) {
     ProfScope ps(st, "attn_combine", (double)BH * c.QB * c.splits * 16 * ATT_PSTRIDE * 4, 0);
@@ -1392,7 +1413,6 @@ extern "C" int64_t ptts_profile_stop(ptts_engine *e, char *h_out, int64_t capaci
 
 // ------------------------------------------------------------------------------------------------
 // Single-launch flow MLP (ptts_flow.h).  Geometry per state: RT row tiles per cluster, NG clusters of FDF workgroups.
-static constexpr int kFlowMaxCUs = 128;  // half of the 256 CUs: the codec stream (and its CU share) stays alive beside it
 static bool flow_cluster_ok(const ptts_engine *e, const ptts_lm_state *s) {
   const ptts_config &c = e->cfg;
   const int FDF = c.flow_dim / 16, LF = c.ldim / 16;
@@ -1402,8 +1422,8 @@ static bool flow_cluster_ok(const ptts_engine *e, const ptts_lm_state *s) {
   if (!e->input_proj.bias || !e->fin.bias) return false;
   for (auto &r : e->res) if (!r.l0.bias || !r.l2.bias) return false;
   // every workgroup of the launch must be resident at once (they wait for each other) and a 9-wave workgroup fills a
-  // CU: the grid is capped at kFlowMaxCUs workgroups (larger batches loop over row groups inside the kernel)
-  return FDF <= kFlowMaxCUs;
+  // CU: the grid is capped at opt_flow_max_cus workgroups (default 128: half the chip, so a codec kernel always has CUs left) (larger batches loop over row groups inside the kernel)
+  return FDF <= e->opt_flow_max_cus;
 }
 // (re)allocates the per-state buffers whose size depends on the number of LSD steps; never called during capture
 static int ensure_flow(ptts_engine *e, ptts_lm_state *s, int steps, hipStream_t st) {
@@ -1442,7 +1462,7 @@ static void launch_flow_cluster(hipStream_t st, ptts_engine *e, ptts_lm_state *s
   const int FDF = c.flow_dim / 16, LF = c.ldim / 16;
   FlowArgs fa;
   memset(&fa, 0, sizeof fa);
-  fa.MT = s->MT; fa.M = s->B; fa.NG = s->flow_ng; fa.NCL = std::max(1, std::min(s->flow_ng, kFlowMaxCUs / FDF)); fa.FDF = FDF; fa.LF = LF; fa.AF = e->adaln.NT;
+  fa.MT = s->MT; fa.M = s->B; fa.NG = s->flow_ng; fa.NCL = std::max(1, std::min(s->flow_ng, e->opt_flow_max_cus / FDF)); fa.FDF = FDF; fa.LF = LF; fa.AF = e->adaln.NT;
   fa.depth = c.flow_depth; fa.steps = lsd_steps; fa.ldim = c.ldim;
   fa.w_in = e->input_proj.w; fa.b_in = e->input_proj.bias;
   for (int r = 0; r < c.flow_depth; ++r) {
@@ -1890,8 +1910,8 @@ static int mimi_enqueue_h(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, co
     SITE("mimi.attn");
     {
       const double keys = (double)B * std::min(e->ring, (s->h_frame + 1) * st16);
-      ProfScope ps(st, "attn@" + std::to_string((long)BH * s->splits * 64), keys * c.m_heads * 64 * 4 * 2 + 6.0 * M16 * C, 4.0 * keys * c.m_heads * 64 * 16);
-      attn_kernel<<<dim3(BH, 1, s->splits), 64, 0, st>>>(at);
+      ProfScope ps(st, "attn@" + std::to_string((long)BH * s->splits * 64 * attn_nw(BH)), keys * c.m_heads * 64 * 4 * 2 + 6.0 * M16 * C, 4.0 * keys * c.m_heads * 64 * 16);
+      launch_attn(st, at, BH);
     }
     if (s->splits > 1) {
       ProfScope ps(st, "attn_combine", (double)BH * s->splits * 16 * ATT_PSTRIDE * 4, 0);
@@ -2064,11 +2084,14 @@ extern "C" int ptts_mimi_decode(ptts_engine *e, ptts_mimi_state *s, const float 
 
 // ------------------------------------------------------------------------------------------------
 // Tile autotuning for one batch size (see Tuner).  Runs on scratch states; the caller's states are untouched.
-extern "C" int ptts_tune(ptts_engine *e, int32_t B, void *stream) {
+extern "C" int ptts_tune(ptts_engine *e, int32_t B, void *stream) { return ptts_tune_streams(e, B, stream, stream); }
+// The FlowLM step is tuned on `lm_stream`, the codec frame on `codec_stream`: with CU-masked streams
+// (ptts_stream_create_masked) each stage gets the tiles that are fastest on ITS share of the chip.
+extern "C" int ptts_tune_streams(ptts_engine *e, int32_t B, void *lm_stream, void *codec_stream) {
   if (!e || B < 1) return fail(-1, "bad argument");
   ENGINE_LOCK(e);
   HIPCHK(hipSetDevice(e->device));
-  hipStream_t st = S(e, stream);
+  hipStream_t st = S(e, lm_stream), st2 = S(e, codec_stream);
   Tuner &t = *e->tuner;
   ptts_lm_state *ls = nullptr;
   ptts_mimi_state *ms = nullptr;
@@ -2086,10 +2109,11 @@ extern "C" int ptts_tune(ptts_engine *e, int32_t B, void *stream) {
     e->prof.on = false;
     t.active = true;
     rc = ptts_lm_decode_step(e, ls, nullptr, nullptr, 1, 1e30f, nullptr, nullptr, nullptr, st);
-    if (rc == 0) rc = ptts_mimi_decode(e, ms, ls->lat, nullptr, st);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == 0) rc = fail(-2, "tune: stream error");
+    if (rc == 0) rc = ptts_mimi_decode(e, ms, ls->lat, nullptr, st2);
     t.active = false;
     e->prof.on = prof;
-    if (hipStreamSynchronize(st) != hipSuccess && rc == 0) rc = fail(-2, "tune: stream error");
+    if (hipStreamSynchronize(st2) != hipSuccess && rc == 0) rc = fail(-2, "tune: stream error");
   }
   if (t.e0) hipEventDestroy(t.e0);
   if (t.e1) hipEventDestroy(t.e1);
@@ -2418,6 +2442,10 @@ extern "C" int ptts_set_option(ptts_engine *e, const char *key, int32_t value) {
   if (k == "flow_cluster") e->opt_flow_cluster = value != 0;
   else if (k == "lm_cluster") e->opt_lm_cluster = value != 0;
   else if (k == "k_rotate") e->opt_k_rotate = value != 0;
+  else if (k == "flow_max_cus") {
+    if (value < 8 || value > 256) return fail(-1, "flow_max_cus must be in [8, 256]");
+    e->opt_flow_max_cus = value;
+  }
   else return fail(-1, "unknown option " + k);
   return 0;
 }

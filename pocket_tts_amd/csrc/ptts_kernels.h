@@ -1286,31 +1286,65 @@ struct AttnArgs {
 };
 #define ATT_PSTRIDE 80
 
-__device__ __forceinline__ void attn_store_out(const AttnArgs &a, int b, int h, int qb, int nq, int lane, f32x4 o[4],
-                                               float linv_for_row[4]) {
+// Cross-row all-reduce over the four 16-lane rows of a wave on the vector ALU (gfx950 v_permlane16_swap /
+// v_permlane32_swap): lanes c, c + 16, c + 32, c + 48 end up with the max / sum of their four values.  The ds_bpermute
+// path of __shfl_xor costs an LDS round trip (> 100 cycles) per step, in the middle of every tile's dependent chain.
+// (inline asm: ROCm 7.2's clang returns the FIRST result of __builtin_amdgcn_permlane{16,32}_swap in both elements
+// of its result vector - tests/hip/xrow_test - so the builtin cannot be used; the s_nop covers the VALU-write ->
+// permlane-swap hazard the compiler would otherwise pad)
+struct xrow_pair { float a, b; };
+__device__ __forceinline__ xrow_pair xrow_swap16(float x) {
+  xrow_pair r = {x, x};
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(r.a), "+v"(r.b));
+  return r;
+}
+__device__ __forceinline__ xrow_pair xrow_swap32(float x) {
+  xrow_pair r = {x, x};
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(r.a), "+v"(r.b));
+  return r;
+}
+__device__ __forceinline__ float xrow_max(float x) {
+  xrow_pair r = xrow_swap16(x);
+  x = fmaxf(r.a, r.b);
+  r = xrow_swap32(x);
+  return fmaxf(r.a, r.b);
+}
+__device__ __forceinline__ float xrow_sum(float x) {
+  xrow_pair r = xrow_swap16(x);
+  x = r.a + r.b;
+  r = xrow_swap32(x);
+  return r.a + r.b;
+}
+
+// Output of one (query c, 16-wide d group g) lane: o[j][rr] = O[query c][d = 16 g + 4 rr + j]
+__device__ __forceinline__ void attn_store_out(const AttnArgs &a, int b, int h, int qb, int nq, int lane, const f32x4 o[4],
+                                               float linv) {
   const int c = lane & 15, g = lane >> 4;
+  if (c >= nq) return;
+  const size_t m = (size_t)b * a.Tq + 16 * qb + c;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int qi = 4 * g + r;
-    if (qi < nq) {
-      const size_t m = (size_t)b * a.Tq + 16 * qb + qi;
-      f32x4 v;
-      v.x = o[0][r] * linv_for_row[r];
-      v.y = o[1][r] * linv_for_row[r];
-      v.z = o[2][r] * linv_for_row[r];
-      v.w = o[3][r] * linv_for_row[r];
-      // column n = h*64 + 4c + j -> fragment 4h + c/4, k-group c%4
-      if (a.h16) *(bf16x4 *)((__bf16 *)a.Y + fmh_off(m, h * 64 + 4 * c, a.YF)) = to_bf16x4(v);
-      else *(f32x4 *)(a.Y + (((m >> 4) * a.YF + 4 * h + (c >> 2)) * 64 + 16 * (c & 3) + (m & 15)) * 4) = v;
-    }
+  for (int rr = 0; rr < 4; ++rr) {
+    f32x4 v;
+    v.x = o[0][rr] * linv; v.y = o[1][rr] * linv; v.z = o[2][rr] * linv; v.w = o[3][rr] * linv;
+    // column n = h*64 + 16g + 4rr + j -> fragment 4h + g, k-group rr
+    if (a.h16) *(bf16x4 *)((__bf16 *)a.Y + fmh_off(m, h * 64 + 16 * g + 4 * rr, a.YF)) = to_bf16x4(v);
+    else *(f32x4 *)(a.Y + (((m >> 4) * a.YF + 4 * h + g) * 64 + 16 * rr + (m & 15)) * 4) = v;
   }
 }
 
-__global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
+// NW waves of a workgroup share one (sequence, head, query block, key split): each streams a contiguous run of the
+// split's key tiles and the partial (o, m, l) meet in LDS in fixed wave order (as in attn_decode_kernel), so a codec
+// frame reaches ~2048 waves without partial buffers and without the combine launch.
+//   S^T = K Q^T  : lane (c = query, g) holds s[r] = score(key 4g + r, query c)
+//   O^T = V^T P^T: A = V[key 4g + r'][4 i + j] (the lane's own 16-byte V load), B = p[r'] -> lane (c, g) accumulates
+//                  O[query c][16 g + 4 rr + j]: the online-softmax rescale and the final 1/l are per-LANE scalars,
+//                  and the only cross-lane traffic of a tile is one max and one sum over the four rows (xrow_*).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
   if constexpr (PTTS_ABLATE & 128) return;
   const int bh = blockIdx.x, qb = blockIdx.y, sp = blockIdx.z;
   const int b = bh / a.H, h = bh - b * a.H;
-  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   const int off = a.offset[b];
   const int q0 = off + 16 * qb;
   const int nq = min(16, a.Tq - 16 * qb);
@@ -1318,8 +1352,10 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
   const int khi = q0 + nq;
   const int tile_lo = klo >> 4, tile_hi = (khi + 15) >> 4;
   const int per = (tile_hi - tile_lo + a.splits - 1) / a.splits;
-  const int ts = tile_lo + sp * per;
-  const int te = min(tile_hi, ts + per);
+  const int gs = tile_lo + sp * per, ge = min(tile_hi, gs + per);  // the workgroup's tiles
+  const int perw = (max(ge - gs, 0) + NW - 1) / NW;
+  const int ts = gs + wave * perw;
+  const int te = min(ge, ts + perw);                                 // this wave's tiles
 
   f32x4 qf[4];
 #pragma unroll
@@ -1349,15 +1385,15 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
     const int p0 = tile * 16;
     // four independent accumulators (one per 16-wide slice of d), issued round-robin: no MFMA waits for
     // the 40-cycle dependent-accumulator latency
-    f32x4 sp[4];
+    f32x4 sp4[4];
 #pragma unroll
-    for (int df = 0; df < 4; ++df) sp[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int df = 0; df < 4; ++df) sp4[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int cidx = 0; cidx < 4; ++cidx)
 #pragma unroll
       for (int df = 0; df < 4; ++df)
-        sp[df] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf4[df][cidx], qf[df][cidx], sp[df], 0, 0, 0);
-    const f32x4 s = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+        sp4[df] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf4[df][cidx], qf[df][cidx], sp4[df], 0, 0, 0);
+    const f32x4 s = (sp4[0] + sp4[1]) + (sp4[2] + sp4[3]);
     // s[r] = score(key p0 + 4g + r, query c)
     bool ok[4];
     float mx = NEG_BIG;
@@ -1367,8 +1403,7 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
       ok[r] = (c < nq) && (pk <= pq) && (a.ctx <= 0 || pq - pk < a.ctx);
       mx = ok[r] ? fmaxf(mx, s[r]) : mx;
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = xrow_max(mx);
     const float m_new = fmaxf(m_run, mx);
     const float alpha = expf(m_run - m_new);
     f32x4 p;
@@ -1378,23 +1413,18 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
       p[r] = ok[r] ? expf(s[r] - m_new) : 0.f;
       ps += p[r];
     }
-    ps += __shfl_xor(ps, 16);
-    ps += __shfl_xor(ps, 32);
+    ps = xrow_sum(ps);
     l_run = l_run * alpha + ps;
     m_run = m_new;
-    // rescale the accumulator rows (query 4g + r lives in lane 4g + r of the score layout)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] *= alpha;
+    // O^T[d = 4i + j][query] += sum_key V[key][4i + j] P[query][key]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float ar = __shfl(alpha, 4 * g + r);
-      o[0][r] *= ar; o[1][r] *= ar; o[2][r] *= ar; o[3][r] *= ar;
-    }
-    // O[query][d = 4c' + j] += sum_key P[query][key] V[key][4c' + j]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], vf4[r].x, o[0], 0, 0, 0);
-      o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], vf4[r].y, o[1], 0, 0, 0);
-      o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], vf4[r].z, o[2], 0, 0, 0);
-      o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], vf4[r].w, o[3], 0, 0, 0);
+      o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf4[r].x, p[r], o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf4[r].y, p[r], o[1], 0, 0, 0);
+      o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf4[r].z, p[r], o[2], 0, 0, 0);
+      o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf4[r].w, p[r], o[3], 0, 0, 0);
     }
   };
   // Three rotating register tiles: the K/V of the next TWO key tiles (16 KB per wave) are in flight while a tile's
@@ -1423,24 +1453,45 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
     if (tile < te) process(tile, k0, v0);
     if (tile + 1 < te) process(tile + 1, k1, v1);
   }
+  if constexpr (NW > 1) {
+    // a wave without tiles has m = NEG_BIG, l = 0, o = 0 and weight exp(NEG_BIG - M) = 0
+    __shared__ f32x4 so[NW][4][64];
+    __shared__ float sm[NW][16], sl[NW][16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) so[wave][j][lane] = o[j];
+    if (g == 0) { sm[wave][c] = m_run; sl[wave][c] = l_run; }
+    __syncthreads();
+    if (wave != 0) return;
+    float M = sm[0][c];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) M = fmaxf(M, sm[w][c]);
+    float L = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float e = expf(sm[w][c] - M);
+      L += sl[w][c] * e;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] += so[w][j][lane] * e;
+    }
+    m_run = M;
+    l_run = L;
+  }
 
   if (a.splits == 1) {
-    float linv[4];
-    const float li = 1.0f / l_run;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) linv[r] = __shfl(li, 4 * g + r);
-    attn_store_out(a, b, h, qb, nq, lane, o, linv);
+    attn_store_out(a, b, h, qb, nq, lane, o, 1.0f / l_run);
   } else {
-    float *pp = a.part + (((size_t)bh * a.QB + qb) * a.splits + sp) * 16 * ATT_PSTRIDE;
+    float *pp = a.part + (((size_t)bh * a.QB + qb) * a.splits + sp) * 16 * ATT_PSTRIDE + c * ATT_PSTRIDE;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int rr = 0; rr < 4; ++rr) {
       f32x4 v;
-      v.x = o[0][r]; v.y = o[1][r]; v.z = o[2][r]; v.w = o[3][r];
-      *(f32x4 *)(pp + (4 * g + r) * ATT_PSTRIDE + 4 * c) = v;
+      v.x = o[0][rr]; v.y = o[1][rr]; v.z = o[2][rr]; v.w = o[3][rr];
+      *(f32x4 *)(pp + 16 * g + 4 * rr) = v;
     }
     if (g == 0) {
-      pp[c * ATT_PSTRIDE + 64] = m_run;
-      pp[c * ATT_PSTRIDE + 65] = l_run;
+      pp[64] = m_run;
+      pp[65] = l_run;
     }
   }
 }
@@ -1568,6 +1619,152 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(AttnArgs a) {
     float *pp = a.part + (((size_t)bh * a.QB) * a.splits + sp) * 16 * ATT_PSTRIDE;  // row 0 of the block
     *(f32x4 *)(pp + 4 * c) = o;
     if (c == 0) {
+      pp[64] = m_run;
+      pp[65] = l_run;
+    }
+  }
+}
+
+// Decode-step attention, second layout (round 2).  The first kernel above spends its time in the memory system's
+// latency, not its bandwidth: two 8 KB tiles in flight per wave, and per tile a chain of ~14 cross-row lane exchanges
+// (LDS crossbar) that nothing hides at one wave per SIMD.  Here
+//   * every load instruction reads 1 KB CONTIGUOUS (lane l: 16 B at l * 16 of a quarter tile): lane (rw = l / 16,
+//     cc = l % 16) of load i holds key 4 i + rw, dims 4 cc .. 4 cc + 3 - of K and of V alike;
+//   * a score is a sum over the 16 lanes of a DPP row: four v_add_f32 row_ror, no LDS crossbar;
+//   * each row rw keeps its OWN online-softmax state (m, l, o) over the keys = rw mod 4; the four states are merged
+//     once, after the stream, so the loop has no cross-row traffic at all;
+//   * D register tiles rotate (D - 1 tiles = (D - 1) * 8 KB in flight per wave; one wave per SIMD leaves 512 VGPRs).
+// Same tiles, masks, key split over NW waves, LDS merge, partial buffers and output layout as attn_decode_kernel.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float x) {  // sum over the 16 lanes of a DPP row, in every lane of it
+  x += dpp_mov_f<0x128>(x);  // row_ror:8
+  x += dpp_mov_f<0x124>(x);  // row_ror:4
+  x += dpp_mov_f<0x122>(x);  // row_ror:2
+  x += dpp_mov_f<0x121>(x);  // row_ror:1
+  return x;
+}
+struct KvTile { f32x4 k[4], v[4]; };
+
+template <int NW, int D>
+__global__ __launch_bounds__(64 * NW) void attn_decode2_kernel(AttnArgs a) {
+  if constexpr (PTTS_ABLATE & 128) return;
+  const int bh = blockIdx.x, sp = blockIdx.z;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cc = lane & 15, rw = lane >> 4;
+  const int pq = a.offset[b];  // position of the query; keys klo .. pq
+  const int klo = a.ctx > 0 ? max(0, pq - a.ctx + 1) : 0;
+  const int tile_lo = klo >> 4, tile_hi = (pq + 16) >> 4;
+  const int per = (tile_hi - tile_lo + a.splits - 1) / a.splits;
+  const int gs = tile_lo + sp * per, ge = min(tile_hi, gs + per);  // the workgroup's tiles
+  const int perw = (max(ge - gs, 0) + NW - 1) / NW;
+  const int ts = gs + wave * perw;
+  const int te = min(ge, ts + perw);                                 // this wave's tiles
+
+  // q[4 cc .. 4 cc + 3] / sqrt(64): row 0 of the query block, fragment cc / 4, k-group cc % 4
+  const f32x4 q = *(const f32x4 *)(a.Q + ((((size_t)bh * a.QB) * 4 + (cc >> 2)) * 64 + 16 * (cc & 3)) * 4) * 0.125f;
+  const float *Kb = a.Kc + (size_t)bh * a.cap * 64 + lane * 4;
+  const float *Vb = a.Vc + (size_t)bh * a.cap * 64 + lane * 4;
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  float m_run = NEG_BIG, l_run = 0.f;
+
+  auto load_tile = [&](int tile, KvTile &t) {
+    const int p0 = tile * 16;
+    const size_t base = (size_t)(a.ring ? (p0 % a.ring) : p0) * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.k[i] = __builtin_nontemporal_load((const f32x4 *)(Kb + base + 256 * i));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.v[i] = __builtin_nontemporal_load((const f32x4 *)(Vb + base + 256 * i));
+  };
+  auto process = [&](int tile, const KvTile &t) {
+    float s[4];
+    bool ok[4];
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s[i] = row16_sum((t.k[i].x * q.x + t.k[i].y * q.y) + (t.k[i].z * q.z + t.k[i].w * q.w));
+      const int pk = tile * 16 + 4 * i + rw;
+      ok[i] = (pk <= pq) && (a.ctx <= 0 || pq - pk < a.ctx);
+      mx = ok[i] ? fmaxf(mx, s[i]) : mx;
+    }
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = expf(m_run - m_new);
+    o *= alpha;
+    float ps = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float p = ok[i] ? expf(s[i] - m_new) : 0.f;
+      ps += p;
+      o += t.v[i] * p;
+    }
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+  };
+  KvTile t[D];
+  if (ts < te) {
+    const int tl = te - 1;
+    // unconditional, clamped prefetches and one back-edge (see attn_kernel: a load behind a branch serialises the
+    // compiler's wait counts)
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) load_tile(min(ts + j, tl), t[j]);
+    int tile = ts;
+    for (; tile + D <= te; tile += D) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        load_tile(min(tile + j + D - 1, tl), t[(j + D - 1) % D]);
+        process(tile + j, t[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j)
+      if (tile + j < te) process(tile + j, t[j]);
+  }
+  // merge the four row states (a row without a valid key has m = NEG_BIG and weight exp(NEG_BIG - M) = 0)
+  float M = fmaxf(m_run, __shfl_xor(m_run, 16));
+  M = fmaxf(M, __shfl_xor(M, 32));
+  {
+    const float e = expf(m_run - M);
+    l_run *= e;
+    o *= e;
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] += __shfl_xor(o[j], 16);
+      o[j] += __shfl_xor(o[j], 32);
+    }
+    m_run = M;
+  }
+  if constexpr (NW > 1) {
+    __shared__ f32x4 so[NW][16];
+    __shared__ float sm[NW], sl[NW];
+    if (rw == 0) so[wave][cc] = o;
+    if (lane == 0) { sm[wave] = m_run; sl[wave] = l_run; }
+    __syncthreads();
+    if (wave != 0) return;
+    float MM = sm[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) MM = fmaxf(MM, sm[w]);
+    float L = 0.f;
+    f32x4 O = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float e = expf(sm[w] - MM);
+      L += sl[w] * e;
+      O += so[w][cc] * e;
+    }
+    o = O; m_run = MM; l_run = L;
+  }
+  if (rw != 0) return;
+  if (a.splits == 1) {
+    const size_t m = (size_t)b * a.Tq;
+    *(f32x4 *)(a.Y + (((m >> 4) * a.YF + 4 * h + (cc >> 2)) * 64 + 16 * (cc & 3) + (m & 15)) * 4) = o * (1.0f / l_run);
+  } else {
+    float *pp = a.part + (((size_t)bh * a.QB) * a.splits + sp) * 16 * ATT_PSTRIDE;  // row 0 of the block
+    *(f32x4 *)(pp + 4 * cc) = o;
+    if (cc == 0) {
       pp[64] = m_run;
       pp[65] = l_run;
     }

@@ -99,9 +99,20 @@ static void sweep(const char *name, int M, int N, int K, int ntaps, int T) {
   for (size_t i = 0; i < r.size() && i < 7; ++i) printf(" %s %.1fus(%dx%d)", r[i].cfg.c_str(), r[i].us, r[i].gx, r[i].gy);
   printf(" | best %.1f TF\n", fl / r[0].us * 1e-6);
 }
-int main() {
+int main(int argc, char **argv) {
   hipStreamCreate(&g_st);
   hipMalloc(&g_buf, (size_t)3 << 30); hipMemset(g_buf, 0, (size_t)3 << 30);
+  if (argc > 1 && !strcmp(argv[1], "pmc")) {  // a handful of (shape, tile) pairs for a rocprofv3 --pmc pass
+    std::vector<Res> r;
+    const int R = 1024;
+    run_lds<4, 2, 2>(r, 30 * R, 256, 128, 2, 480);   // seanet.convtr3
+    run_lds<4, 4, 2>(r, R, 2048, 512, 1, 16);        // mimi.ff1
+    run<2, 4, 4, 1, 1>(r, R, 512, 512, 7, 16);       // seanet.conv0
+    run_lds<4, 4, 2>(r, 30 * R, 64, 128, 3, 480);    // seanet.res2a
+    run_lds<8, 8, 2>(r, 30 * R, 256, 128, 2, 480);   // convtr3 on the large tile
+    for (auto &x : r) printf("%s %.1f us (%dx%d)\n", x.cfg.c_str(), x.us, x.gx, x.gy);
+    return 0;
+  }
   const int Bs[] = {64};
   for (int B : Bs) {
     printf("---- batch %d\n", B);

@@ -172,7 +172,7 @@ static void test_gemm_lnfold(int M, int N, int K, int cfg) {
   report(nm, maxerr(g2, Y), 2e-4 * std::sqrt((double)K / 64));
 }
 
-static void test_attn(int BH, int Tq, int off, int ctx, int ring, int splits) {
+static void test_attn(int BH, int Tq, int off, int ctx, int ring, int splits, int nw = 1) {
   const int H = 2; int B = BH / H;
   int T = off + Tq, cap = ring ? ring : cdiv(T, 16) * 16, QB = cdiv(Tq, 16);
   std::vector<float> Q((size_t)BH * Tq * 64), K((size_t)BH * T * 64), V((size_t)BH * T * 64), O((size_t)B * Tq * H * 64);
@@ -204,12 +204,14 @@ static void test_attn(int BH, int Tq, int off, int ctx, int ring, int splits) {
   AttnArgs a; memset(&a, 0, sizeof a);
   a.Q = dev(Qb); a.Kc = dev(Kc); a.Vc = dev(Vc); a.offset = dev(offs); a.H = H; a.Tq = Tq; a.QB = QB; a.cap = cap; a.ring = ring; a.ctx = ctx; a.splits = splits;
   a.part = dzero<float>((size_t)BH * QB * splits * 16 * ATT_PSTRIDE); a.Y = dzero<float>((size_t)MT * YF * 256); a.YF = YF;
-  attn_kernel<<<dim3(BH, QB, splits), 64>>>(a);
+  if (nw == 4) attn_kernel<4><<<dim3(BH, QB, splits), 256>>>(a);
+  else if (nw == 2) attn_kernel<2><<<dim3(BH, QB, splits), 128>>>(a);
+  else attn_kernel<1><<<dim3(BH, QB, splits), 64>>>(a);
   if (splits > 1) attn_combine_kernel<<<dim3(BH, QB), 256>>>(a);
   float *dY = dzero<float>((size_t)B * Tq * H * 64);
   from_fm_kernel<<<cdiv((long)B * Tq * H * 16, 256), 256>>>(a.Y, dY, B * Tq, H * 64, YF, 0);
   CK(hipDeviceSynchronize());
-  char nm[128]; snprintf(nm, sizeof nm, "attn BH=%d Tq=%d off=%d ctx=%d ring=%d sp=%d", BH, Tq, off, ctx, ring, splits);
+  char nm[128]; snprintf(nm, sizeof nm, "attn BH=%d Tq=%d off=%d ctx=%d ring=%d sp=%d nw=%d", BH, Tq, off, ctx, ring, splits, nw);
   report(nm, maxerr(host(dY, O.size()), O), 2e-5);
 }
 
@@ -241,6 +243,8 @@ int main() {
   test_attn(6, 16, 0, 40, 64, 1);
   test_attn(6, 16, 64, 40, 64, 2);
   test_attn(2, 16, 1600, 250, 272, 3);
+  test_attn(2, 39, 20, 0, 0, 1, 2); test_attn(2, 39, 20, 0, 0, 2, 4); test_attn(6, 16, 64, 40, 64, 1, 4);
+  test_attn(2, 16, 1600, 250, 272, 1, 4); test_attn(2, 16, 1600, 250, 272, 2, 2); test_attn(4, 7, 3, 0, 0, 1, 4);
   printf(fails ? "FAILED (%d)\n" : "ALL OK\n", fails);
   return fails ? 1 : 0;
 }
