@@ -199,6 +199,11 @@ int ptts_tune_import(ptts_engine *e, const char *text);
  *                                           DESIGN.md section 3), 0 = five launches per layer
  *   "k_rotate"      [PTTS_K_ROTATE, 0]      1 = K-split GEMM workgroups start their K loop at a column-block dependent
  *                                           chunk (spreads the re-reads of the shared activation rows over L2 channels)
+ *   "fuse_res"      [PTTS_FUSE_RES, 1]      1 = a SEANet residual block (k3 conv, ELU, 1x1 conv, skip) of decoder stages 2 and 3
+ *                                           is ONE launch, the hidden activation staying in LDS; 0 = two launches
+ *   "codec_lds_target" [PTTS_CODEC_LDS_TARGET, 45056]  the codec's GEMM launches pad their LDS request to this many bytes
+ *                                           per workgroup (0 = off): fewer codec workgroups per CU, so the FlowLM stream's
+ *                                           short dependent kernels find free wave slots (+2 % pipelined throughput)
  *   "flow_max_cus"  [-, 128]                resident workgroups of the cooperative flow launch (8..256): at most the number
  *                                           of CUs its stream may use (a CU-masked FlowLM stream needs it lowered)
  * Applies to steps enqueued / graphs captured after the call.  Returns -1 for an unknown key. */
@@ -211,6 +216,11 @@ int ptts_lm_state_error(ptts_lm_state *s, void *stream);
  * Destroy with ptts_stream_destroy after the work queued on it has finished. */
 int ptts_stream_create_masked(ptts_engine *e, int32_t cu_lo, int32_t cu_hi, void **out_stream);
 int ptts_stream_destroy(void *stream);
+/* 1 if work queued on the two streams runs concurrently, 0 if the runtime put them on the same hardware queue (HIP
+ * multiplexes streams onto GPU_MAX_HW_QUEUES queues, default 4, round-robin at creation; such a pair executes strictly
+ * in turn).  Callers that pipeline the FlowLM step and the codec frame on two streams check the pair once and pick
+ * another stream on 0.  Synchronises both streams; costs ~0.5 ms. */
+int ptts_streams_overlap(ptts_engine *e, void *stream_a, void *stream_b);
 int ptts_sync(ptts_engine *e, void *stream);
 void *ptts_engine_stream(ptts_engine *e);
 /* asynchronous device -> pinned-host copy on `stream` (PCM chunks, EOS flags) */

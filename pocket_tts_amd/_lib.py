@@ -76,6 +76,7 @@ PROTOTYPES = {
     "ptts_mimi_set_pcm_i16": (C.c_int, [_P, _P]),
     "ptts_tune": (C.c_int, [_P, C.c_int32, _P]),
     "ptts_tune_streams": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "ptts_streams_overlap": (C.c_int, [_P, _P, _P]),
     "ptts_tune_prefill": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "ptts_tune_log": (C.c_char_p, [_P]),
     "ptts_tune_clear": (None, [_P]),

@@ -125,6 +125,9 @@ struct ptts_engine {
   int opt_lm_cluster = 0;  // measured slower than five launches per layer: kept as an experiment
   LmLayerP *lm_table = nullptr;  // device table of the FlowLM layers for lm_cluster_kernel (null: not eligible)
   int opt_k_rotate = 0;
+  long fuse_res_min_rows = 0;
+  int opt_codec_lds_target = 44 * 1024;  // see lds_pad()
+  int opt_fuse_res = 1;  // SEANet residual blocks of stages 2 and 3 as one launch each (gemm_lds_kernel<.., NT2>)
   int opt_flow_max_cus = 128;  // resident workgroups of the single-launch flow MLP (<= the CUs its stream may use)
   std::recursive_mutex mu;  // entry points that enqueue work or touch tuner / profiler / LSD tables hold it
   int quant_flags = 0;
@@ -411,23 +414,33 @@ static void launch_cfg_q8(hipStream_t st, const GemmArgs &a, int pre) {
   else gemm_kernel<TN, TM, WK, WN, WM, PRE_NONE, true><<<grid, block, 0, st>>>(a);
 }
 
+// Occupancy cap of the codec's GEMM launches (engine option "codec_lds_target", bytes; 0 = off): they request dynamic LDS
+// up to this total per workgroup, which limits their workgroups per CU to 160 KB / target and leaves wave slots and
+// registers for the FlowLM stream's kernels, whose dependent chain is what the pipelined step waits for.  Measured at
+// batch 64 (tools/ab_env.sh PTTS_CODEC_LDS_TARGET): 0 -> 0.936 ms per step, 44 KB (3 per CU) -> 0.917, 56 KB (2 per CU)
+// -> 0.917; the codec graph alone 0.548 -> 0.554 -> 0.589 ms (tools/ov_ldspad.sh).
+static thread_local int g_lds_target = 0;
+static unsigned lds_pad(int static_bytes) { return g_lds_target > static_bytes ? (unsigned)(g_lds_target - static_bytes) : 0u; }
+
 template <int TN, int TM, int WK, int WN, int WM>
 static void launch_cfg(hipStream_t st, const GemmArgs &a, int pre) {
   dim3 grid(cdiv(a.NT, TN * WN), cdiv(a.MT, TM * WM));
   dim3 block(64 * WK * WN * WM);
+  const unsigned dyn = lds_pad(WK > 1 ? WK * WN * WM * TN * TM * 1024 : 0);
   switch (pre) {
-    case PRE_NONE: gemm_kernel<TN, TM, WK, WN, WM, PRE_NONE><<<grid, block, 0, st>>>(a); break;
-    case PRE_LNFOLD: gemm_kernel<TN, TM, WK, WN, WM, PRE_LNFOLD><<<grid, block, 0, st>>>(a); break;
-    case PRE_LNMOD: gemm_kernel<TN, TM, WK, WN, WM, PRE_LNMOD><<<grid, block, 0, st>>>(a); break;
-    default: gemm_kernel<TN, TM, WK, WN, WM, PRE_ADDSILU><<<grid, block, 0, st>>>(a); break;
+    case PRE_NONE: gemm_kernel<TN, TM, WK, WN, WM, PRE_NONE><<<grid, block, dyn, st>>>(a); break;
+    case PRE_LNFOLD: gemm_kernel<TN, TM, WK, WN, WM, PRE_LNFOLD><<<grid, block, dyn, st>>>(a); break;
+    case PRE_LNMOD: gemm_kernel<TN, TM, WK, WN, WM, PRE_LNMOD><<<grid, block, dyn, st>>>(a); break;
+    default: gemm_kernel<TN, TM, WK, WN, WM, PRE_ADDSILU><<<grid, block, dyn, st>>>(a); break;
   }
 }
 
 template <int BMT, int BNT>
 static void launch_lds(hipStream_t st, const GemmArgs &a, int pre) {
   dim3 grid(cdiv(a.NT, BNT), cdiv(a.MT, BMT));
-  if (pre == PRE_LNFOLD) gemm_lds_kernel<BMT, BNT, 2, PRE_LNFOLD><<<grid, 256, 0, st>>>(a);
-  else gemm_lds_kernel<BMT, BNT, 2, PRE_NONE><<<grid, 256, 0, st>>>(a);
+  const unsigned dyn = lds_pad(2 * (BMT + BNT) * 2 * 1024);
+  if (pre == PRE_LNFOLD) gemm_lds_kernel<BMT, BNT, 2, PRE_LNFOLD><<<grid, 256, dyn, st>>>(a);
+  else gemm_lds_kernel<BMT, BNT, 2, PRE_NONE><<<grid, 256, dyn, st>>>(a);
 }
 
 // Tile selection.  K-split configs (TM row tiles per wave, 4 waves split K, LDS-reduced) give NT x ceil(MT/TM)
@@ -650,6 +663,23 @@ static void launch_gemm(hipStream_t st, const GemmArgs &a_in, int pre) {
   launch_by_cfg(st, a, pre, cfg);
 }
 
+// k3 conv + ELU + 1x1 conv + skip of a SEANet residual block in one launch (a = the k3 conv's arguments with Y / R
+// already describing the block's output and skip input)
+static bool resblock_fusable(const Lin &A, const Lin &Bl, int MT) {
+  return !A.wq && !Bl.wq && A.bias && Bl.bias && Bl.ntaps == 1 && Bl.KF == A.NT && A.KF % 2 == 0 && MT >= 4 &&
+         ((A.NT == 2 && Bl.NT == 4) || (A.NT == 4 && Bl.NT == 8));
+}
+static void launch_resblock(hipStream_t st, GemmArgs a, const Lin &Bl) {
+  a.zeros = g_zeros;
+  a.W2 = Bl.w; a.bias2 = Bl.bias;
+  const double M = a.M, K = a.KF * 16.0, N = a.NT * 16.0, N2 = Bl.NT * 16.0;
+  ProfScope ps(st, std::string(a.NT == 2 ? "resblock<2,4>" : "resblock<4,8>") + "@" + std::to_string((long)cdiv(a.MT, 4) * 256),
+               4.0 * (N * K + N2 * N + M * a.CF * 16.0 + 2.0 * M * N2), 2.0 * M * N * K + 2.0 * M * N2 * N);
+  dim3 grid(1, cdiv(a.MT, 4));
+  if (a.NT == 2) gemm_lds_kernel<4, 2, 2, PRE_NONE, 2, 4><<<grid, 256, lds_pad(24 * 1024), st>>>(a);
+  else gemm_lds_kernel<4, 4, 2, PRE_NONE, 2, 8><<<grid, 256, lds_pad(32 * 1024), st>>>(a);
+}
+
 static void bind_engine(ptts_engine *e) {
   g_zeros = e->zeros;
   g_tuner = e->tuner;
@@ -826,6 +856,8 @@ extern "C" int ptts_create_ex(const ptts_config *cfg, const ptts_tensor *tensors
   if (const char *v = getenv("PTTS_FLOW_CLUSTER")) e->opt_flow_cluster = atoi(v) != 0;
   if (const char *v = getenv("PTTS_LM_CLUSTER")) e->opt_lm_cluster = atoi(v) != 0;
   if (const char *v = getenv("PTTS_K_ROTATE")) e->opt_k_rotate = atoi(v) != 0;
+  if (const char *v = getenv("PTTS_FUSE_RES")) e->opt_fuse_res = atoi(v) != 0;
+  if (const char *v = getenv("PTTS_CODEC_LDS_TARGET")) e->opt_codec_lds_target = std::max(0, std::min(atoi(v), 64 * 1024));
   const int rc = build_engine(e, tensors, n);
   if (rc < 0) {  // missing / ill-shaped tensor, HIP error: release what was built so far
     const std::string msg = g_err;
@@ -1993,6 +2025,7 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
   if (e->codec_bf16) return mimi_enqueue_h(st, e, s, d_latent, d_pcm);
   const ptts_config &c = e->cfg;
   bind_engine(e);
+  struct LdsScope { LdsScope(int t) { g_lds_target = t; } ~LdsScope() { g_lds_target = 0; } } lds_scope(e->opt_codec_lds_target);
   const int B = s->B, C = c.m_dim, CF = C / 16, LF = c.ldim / 16, st16 = c.upsample_stride;
   SITE("mimi.prologue");  // de-normalise + quantizer 1x1 conv + depthwise x16 upsample + RoPE table: one launch
   {
@@ -2042,6 +2075,18 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
     a.Y = s->cbuf[i]; a.Ydstride = s->c_stride[i]; a.YF = cout / 16; a.act = ACT_ELU;
     a.Yraw = s->craw[i]; a.Yrawdstride = 0;  // raw value = the resnet block's skip input
     launch_gemm(st, a, PRE_NONE);
+    if (e->opt_fuse_res && resblock_fusable(e->res_a[i], e->res_b[i], MTout) && (long)MTout * 16 >= e->fuse_res_min_rows) {
+      SITE(sn[i][1]);
+      a = mk_gemm(e->res_a[i], s->cbuf[i], cout / 16, MTout, B * Tout);
+      a.Xdstride = s->c_stride[i]; a.T = Tout; a.par = s->frame; a.act = ACT_ELU;
+      a.R = s->craw[i]; a.Rdstride = 0; a.RF = cout / 16; a.act2 = ACT_ELU;
+      a.Y = s->sbuf[i]; a.Ydstride = s->s_stride[i]; a.YF = cout / 16;
+      launch_resblock(st, a, e->res_b[i]);
+      xin = s->sbuf[i];
+      xds = s->s_stride[i];
+      mult /= 2;
+      continue;
+    }
     SITE(sn[i][1]);
     a = mk_gemm(e->res_a[i], s->cbuf[i], cout / 16, MTout, B * Tout);
     a.Xdstride = s->c_stride[i]; a.T = Tout; a.par = s->frame;
@@ -2442,6 +2487,11 @@ extern "C" int ptts_set_option(ptts_engine *e, const char *key, int32_t value) {
   if (k == "flow_cluster") e->opt_flow_cluster = value != 0;
   else if (k == "lm_cluster") e->opt_lm_cluster = value != 0;
   else if (k == "k_rotate") e->opt_k_rotate = value != 0;
+  else if (k == "fuse_res") e->opt_fuse_res = value != 0;
+  else if (k == "codec_lds_target") {
+    if (value < 0 || value > 64 * 1024) return fail(-1, "codec_lds_target must be in [0, 65536]");
+    e->opt_codec_lds_target = value;
+  }
   else if (k == "flow_max_cus") {
     if (value < 8 || value > 256) return fail(-1, "flow_max_cus must be in [8, 256]");
     e->opt_flow_max_cus = value;
@@ -2477,6 +2527,39 @@ extern "C" int ptts_stream_create_masked(ptts_engine *e, int32_t cu_lo, int32_t 
   HIPCHK(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()));
   *out = (void *)st;
   return 0;
+}
+// Do two streams run concurrently?  HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4,
+// assigned round-robin at creation): two streams that share a queue execute strictly one after the other, and a
+// pipeline whose FlowLM and codec streams collide loses its whole overlap (measured: 0.88 -> 1.15 ms per step, in about
+// one of four stream pairs).  Two 200 us single-workgroup spin kernels released together: 1 = overlapped, 0 = serialised.
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();  // 100 MHz
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+extern "C" int ptts_streams_overlap(ptts_engine *e, void *stream_a, void *stream_b) {
+  if (!e) return fail(-1, "null engine");
+  HIPCHK(hipSetDevice(e->device));
+  hipStream_t a = S(e, stream_a), b = S(e, stream_b);
+  if (a == b) return 0;
+  hipEvent_t e0, e1, e2;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
+  HIPCHK(hipStreamSynchronize(a)); HIPCHK(hipStreamSynchronize(b));
+  float worst = 0.f;
+  for (int rep = 0; rep < 2; ++rep) {  // first round also warms the kernel up
+    HIPCHK(hipEventRecord(e0, a));
+    HIPCHK(hipStreamWaitEvent(b, e0, 0));
+    spin_kernel<<<1, 64, 0, a>>>(20000);
+    spin_kernel<<<1, 64, 0, b>>>(20000);
+    HIPCHK(hipEventRecord(e1, a));
+    HIPCHK(hipEventRecord(e2, b));
+    HIPCHK(hipStreamSynchronize(a)); HIPCHK(hipStreamSynchronize(b));
+    float t1 = 0.f, t2 = 0.f;
+    HIPCHK(hipEventElapsedTime(&t1, e0, e1));
+    HIPCHK(hipEventElapsedTime(&t2, e0, e2));
+    worst = std::max(t1, t2);
+  }
+  hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
+  return worst < 0.33f ? 1 : 0;  // 0.2 ms each: ~0.21 overlapped, ~0.41 serialised
 }
 extern "C" int ptts_stream_destroy(void *stream) {
   if (stream) HIPCHK(hipStreamDestroy((hipStream_t)stream));

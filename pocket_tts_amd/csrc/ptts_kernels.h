@@ -134,6 +134,10 @@ struct GemmArgs {
   int ldim;
   // EPI_CONVTR
   int cout, stride;
+  // gemm_lds_kernel<.., NT2 > 0>: the 1x1 conv that follows this conv inside a SEANet residual block, fused into
+  // the same launch (Y / R / YF / RF / Ydstride then describe ITS output and skip input): packed [NT2][NT][64][4]
+  const float *W2, *bias2;
+  int act2;
   // EPI_PCM
   float *pcm;
   int16_t *pcm_i16;  // optional 16-bit copy: (clamp(x, -1, 1) * 32767) truncated, as data/audio.py:79
@@ -745,10 +749,17 @@ __device__ __forceinline__ void wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BMT, int BNT, int KC, int PRE, int NS = 2>
+// NT2 > 0 (fused SEANet residual block, reference seanet.py:12-49: x + conv1x1(elu(conv_k3(elu(x))))): the workgroup owns
+// ALL BNT = NT column tiles of the k3 conv for its 16 * BMT rows, so h = act(conv + bias) never leaves the CU: the
+// accumulators are written to LDS as they are (the MFMA C layout of a 16x16 tile IS the FM operand fragment of the
+// next GEMM), and after one barrier every wave runs the 1x1 conv for its share of the NT2 output column tiles
+// (K = 16 * BNT, weights straight from L2 into registers, fetched at kernel start) and finishes with the residual
+// epilogue.  Saves the launch, the HBM write + read of h and the second kernel's ramp.
+template <int BMT, int BNT, int KC, int PRE, int NS = 2, int NT2 = 0>
 __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
   if constexpr (PTTS_ABLATE & 128) return;
   static_assert(BMT % 4 == 0 && BNT % 2 == 0 && (BNT * KC) % 4 == 0, "tile shape");
+  static_assert(NT2 == 0 || (PRE == PRE_NONE && BMT * BNT <= NS * (BMT + BNT) * KC && NT2 % 4 == 0), "fused tail");
   static_assert(NS >= 2 && NS <= 4, "stage count");
   constexpr int WMT = BMT / 2, WNT = BNT / 2;  // tiles per wave
   constexpr int NX = BMT * KC, NFRAG = (BMT + BNT) * KC;
@@ -836,6 +847,17 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
     for (int i = 0; i < WPW; ++i) GLDS16(wp[i] + (size_t)kf0 * 256, &lds[buf][wslot[i]][0]);
   };
 
+  // fused tail: wave w finishes column tiles w, w + 4, .. of the second layer; its weights are requested now
+  constexpr int T2 = NT2 / 4;
+  f32x4 w2[T2 > 0 ? T2 : 1][BNT];
+  if constexpr (NT2 > 0) {
+#pragma unroll
+    for (int t = 0; t < T2; ++t)
+#pragma unroll
+      for (int k = 0; k < BNT; ++k)
+        w2[t][k] = *(const f32x4 *)(a.W2 + (((size_t)(wave + 4 * t) * BNT + k) * 64 + lane) * 4);
+  }
+
   f32x4 acc[WNT][WMT];
 #pragma unroll
   for (int i = 0; i < WNT; ++i)
@@ -912,6 +934,43 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
       mu[j] = sx[j] * invK;
       rs[j] = 1.0f / sqrtf(fmaxf(sxx[j] * invK - mu[j] * mu[j], 0.f) + a.ln_eps);
     }
+  }
+  if constexpr (NT2 > 0) {
+    // h tile -> LDS, fragment (row tile m, k-fragment n) at hfrag[m * BNT + n]: the stage buffers are free once every
+    // wave has left the K loop
+    f32x4(*hfrag)[64] = &lds[0][0];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < WNT; ++i)
+#pragma unroll
+      for (int j = 0; j < WMT; ++j) {
+        const int n = wn * WNT + i;
+        f32x4 v = acc[i][j];
+        if (a.bias) v += *(const f32x4 *)(a.bias + 16 * n + 4 * (lane >> 4));
+        hfrag[(wm * WMT + j) * BNT + n][lane] = act4(v, a.act);
+      }
+    __syncthreads();
+    GemmArgs a2 = a;
+    a2.bias = a.bias2; a2.act = a.act2; a2.epi = EPI_RES; a2.ls = nullptr;
+#pragma unroll
+    for (int m = 0; m < BMT; ++m) {
+      const int mt = mt0 + m;
+      if (mt >= a.MT) break;
+      f32x4 x[BNT];
+#pragma unroll
+      for (int k = 0; k < BNT; ++k) x[k] = hfrag[m * BNT + k][lane];
+#pragma unroll
+      for (int t = 0; t < T2; ++t) {
+        f32x4 c2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < BNT; ++k)
+#pragma unroll
+          for (int cidx = 0; cidx < 4; ++cidx)
+            c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[t][k][cidx], x[k][cidx], c2, 0, 0, 0);
+        gemm_epilogue(a2, c2, wave + 4 * t, mt, lane, par);
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int i = 0; i < WNT; ++i)

@@ -262,3 +262,18 @@ def test_hip_kernel_unit_tests(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+
+
+def test_pipeline_streams_run_concurrently():
+    """HIP maps streams round-robin onto a few hardware queues; a FlowLM / codec stream pair on ONE queue serialises the
+    pipeline.  `Engine.concurrent_stream` must return a stream that overlaps with the FlowLM stream, whatever the number of
+    streams created before (here: eight pipelines' worth), and the probe itself must see both outcomes' timing scale."""
+    eng = get_engine("tiny")
+    assert not eng.streams_overlap(eng.stream, eng.stream)
+    seen = []
+    keep = []
+    for _ in range(8):
+        s = eng.concurrent_stream(eng.stream)
+        keep.append(s)
+        seen.append(eng.streams_overlap(eng.stream, s))
+    assert all(seen), seen

@@ -1,0 +1,99 @@
+"""Pipeline-aware tile tuning: the library's tuner minimises each GEMM's ISOLATED (cold-cache) time, but in the served
+configuration two streams share the chip and a tile that is fastest alone is not always the one the pipelined step
+wants (smaller grids leave wave slots to the other stream, larger ones finish sooner ..).  This tool starts from the
+isolated-tuned table and does one pass of coordinate descent over the GEMM shapes of one batch size, judging every
+alternative tile by the measured time of whole pipelined utterances (graphs re-captured per trial).
+
+python tools/pipeline_tune.py [batch] [out_file]      (run on the GPU box; prints the changed table lines)"""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from pocket_tts_amd.config import named_config
+from pocket_tts_amd.weights import generate_state_dict
+from pocket_tts_amd.engine import Engine, StepPipeline
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+out = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/tune_pipeline.txt"
+NCFG = 16
+cfg = named_config("en100m")
+eng = Engine(cfg, generate_state_dict(cfg, 0), "cuda:0")
+args = bench.parse([]); args.batch = B
+job = bench.Job(eng, B, args, 0)
+frames = args.frames
+
+
+def recapture():
+    old = job.pipe
+    job.pipe.flush(); job.sync(); torch.cuda.synchronize()
+    job.pipe = StepPipeline(eng, job.st, job.ms, None, 1, float("inf"))
+    for g in old.g_first + old.g_last:
+        eng.graph_destroy(g)
+
+
+def measure(reps=2):
+    best = 1e9
+    for _ in range(reps):
+        job.frame = frames  # utterance boundary
+        job.step(); job.sync(); torch.cuda.synchronize()          # clone + prefill + first step untimed (identical in all trials)
+        t0 = time.perf_counter()
+        for _ in range(frames - 1):
+            job.step()
+        job.sync(); torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / (frames - 1) * 1e3)
+    return best
+
+
+for _ in range(2):
+    measure(1)
+table = {}
+for ln in eng._tune_table():
+    f = ln.split()
+    table[tuple(int(x) for x in f[:13])] = int(f[13])
+# the shapes of THIS batch: FlowLM rows = ceil(B / 16) row tiles, codec rows = B * 16 * {1, 6, 30, 120} / 16
+mts = {(B + 15) // 16, B, 6 * B, 30 * B, 120 * B}
+keys = [k for k in table if k[4] in mts]
+print(f"batch {B}: {len(keys)} shapes, start {measure(3):.4f} ms/step", flush=True)
+
+
+def apply(k, c):
+    eng.lib.ptts_tune_import(eng.handle, (" ".join(str(x) for x in k) + f" {c}\n").encode())
+    recapture()
+
+
+base = measure(3)
+changed = []
+for k in keys:
+    cur = table[k]
+    res = {}
+    for c in range(NCFG):
+        if c == cur:
+            continue
+        apply(k, c)
+        res[c] = measure(2)
+    apply(k, cur)
+    ref = measure(2)
+    base = min(base, ref)
+    c_best = min(res, key=res.get)
+    line = f"NT={k[0]} KF={k[1]} taps={k[3]} MT={k[4]} epi={k[5]} pre={k[6]}: cfg {cur} {ref:.4f} | best alt cfg {c_best} {res[c_best]:.4f}"
+    if res[c_best] < ref * 0.996:
+        # confirm against a fresh baseline before accepting
+        apply(k, c_best)
+        again = measure(3)
+        apply(k, cur)
+        ref2 = measure(3)
+        if again < ref2 * 0.997:
+            apply(k, c_best)
+            table[k] = c_best
+            changed.append((k, cur, c_best, ref2, again))
+            line += f"  -> ACCEPTED ({ref2:.4f} -> {again:.4f})"
+            base = again
+        else:
+            line += f"  (not confirmed: {ref2:.4f} vs {again:.4f})"
+    print(line, flush=True)
+final = measure(3)
+print(f"final {final:.4f} ms/step, {len(changed)} shapes changed", flush=True)
+with open(out, "w") as f:
+    for k, old, new, a, b in changed:
+        f.write(" ".join(str(x) for x in k) + f" {new}\n")
+        print("CHANGED", " ".join(str(x) for x in k), f"{old} -> {new}  ({a:.4f} -> {b:.4f})")
+eng.close()
