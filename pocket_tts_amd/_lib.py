@@ -131,7 +131,8 @@ def load() -> C.CDLL:
     # (two runtimes in one process do not share devices, streams or allocations)
     import torch  # noqa: F401
 
-    lib = C.CDLL(str(LIB_PATH))
+    # PTTS_LIB_PATH: load another build of the same sources (A/B runs of compile-time experiments)
+    lib = C.CDLL(os.environ.get("PTTS_LIB_PATH") or str(LIB_PATH))
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res

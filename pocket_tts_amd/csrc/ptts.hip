@@ -572,6 +572,9 @@ __global__ void flush_read_kernel(const f32x4 *p, size_t n, float *sink) {
 }
 
 static int tune_one(hipStream_t st, const GemmArgs &a, int pre, Tuner &t) {
+  // tiles are timed WITHOUT the codec's occupancy cap: under it the LDS-staged tiles look slower alone and the search drifts
+  // to the register-heavy K-split tiles, which cost the pipelined step 6 % (tools/ab_retune.sh)
+  struct NoCap { int keep; NoCap() : keep(g_lds_target) { g_lds_target = 0; } ~NoCap() { g_lds_target = keep; } } nocap;
   int best = pick_cfg(a);
   float best_ms = 1e30f, heur_ms = 0.f;
   const int heur = best;
@@ -793,12 +796,20 @@ static void run_tr_layer(hipStream_t st, const TrLayer &T, const TrCtx &c) {
       // one query: vector ALU + wave reductions.  The keys of a (sequence, head) are split over the nw waves of ONE
       // workgroup and merged in LDS, so small batches reach ~1024 waves without partial buffers or a combine launch
       const int nw = decode_attn_waves(BH);
-      // small batches (latency-bound): the row-state kernel with no cross-row traffic in its loop (6.0 vs 7.2 us per layer
-      // at batch 1, 221 keys); at >= 1024 (sequence, head) pairs both stream at the same rate and the first one stays
+      // the row-state kernel (no cross-row traffic in its loop).  Small batches: three register tiles (6.0 vs 7.2 us per
+      // layer at batch 1, 221 keys).  >= 1024 (sequence, head) pairs: TWO register tiles - alone it streams at the rate of
+      // the first kernel (attn_decode_kernel, 188 VGPRs, still selectable with PTTS_ATTN_V=1), but at ~110 registers per wave
+      // it leaves the codec stream its occupancy: 0.904 -> 0.877 ms per pipelined step at batch 64 (tools/ab_env.sh
+      // PTTS_ATTN_V; three tiles: 0.881)
       if (nw >= 8) attn_decode2_kernel<8, 3><<<dim3(BH, 1, c.splits), 512, 0, st>>>(at);
       else if (nw == 4) attn_decode2_kernel<4, 3><<<dim3(BH, 1, c.splits), 256, 0, st>>>(at);
       else if (nw == 2) attn_decode2_kernel<2, 3><<<dim3(BH, 1, c.splits), 128, 0, st>>>(at);
-      else attn_decode_kernel<1><<<dim3(BH, 1, c.splits), 64, 0, st>>>(at);
+      else {
+        static const int v = [] { const char *e = getenv("PTTS_ATTN_V"); return e ? atoi(e) : 2; }();  // A/B knob
+        if (v == 1) attn_decode_kernel<1><<<dim3(BH, 1, c.splits), 64, 0, st>>>(at);
+        else if (v == 3) attn_decode2_kernel<1, 3><<<dim3(BH, 1, c.splits), 64, 0, st>>>(at);
+        else attn_decode2_kernel<1, 2><<<dim3(BH, 1, c.splits), 64, 0, st>>>(at);
+      }
     }
     else launch_attn(st, at, BH);
   }

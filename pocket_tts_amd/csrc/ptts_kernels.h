@@ -453,7 +453,16 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
   // MFMAs of chunk c, into a second register set, so the matrix pipe works while the next operands fly.
   // decode (K-split) tiles: as many fragments per round as the register file allows, so that a wave needs
   // few serialized HBM round trips for its cold weight stream
-  constexpr int U0 = (TN * TM == 1) ? 8 : (TN * TM == 2 && WK > 1) ? 8 : (TN * TM <= 4 && WK > 1) ? 4 : 2;
+  // K-split (decode) tiles hold PTTS_KSPLIT_DIV times fewer fragments per round than the register file would allow.
+  // Measured (tools/ab_lib.sh, batch 64 pipelined): DIV 1 (253 VGPRs for the 2x2 tile) 0.935-0.939 ms per step, DIV 2 (173)
+  // 0.905-0.910, DIV 4 (128) 0.920.  A FlowLM GEMM is ~1 wave per SIMD that mostly waits for its weights: at 253
+  // registers it pins HALF of every SIMD's register file while resident and evicts the codec stream's waves; with half
+  // the fragments in flight it is barely slower alone (batch 1: 0.358 -> 0.355 ms per step) and the codec keeps its occupancy.
+#ifndef PTTS_KSPLIT_DIV
+#define PTTS_KSPLIT_DIV 2
+#endif
+  constexpr int U00 = (TN * TM == 1) ? 8 : (TN * TM == 2 && WK > 1) ? 8 : (TN * TM <= 4 && WK > 1) ? 4 : 2;
+  constexpr int U0 = (WK > 1) ? (U00 / PTTS_KSPLIT_DIV >= 1 ? U00 / PTTS_KSPLIT_DIV : 1) : U00;
   constexpr int U = (Q8 && U0 < 4) ? 4 : U0;  // int8 weights arrive four k-fragments per load
   auto load_chunk = [&](auto uc, int kf, f32x4 (*w)[TN], f32x4 (*x)[TM]) {
     constexpr int UU = decltype(uc)::value;
