@@ -201,9 +201,9 @@ int ptts_tune_import(ptts_engine *e, const char *text);
  *                                           chunk (spreads the re-reads of the shared activation rows over L2 channels)
  *   "fuse_res"      [PTTS_FUSE_RES, 1]      1 = a SEANet residual block (k3 conv, ELU, 1x1 conv, skip) of decoder stages 2 and 3
  *                                           is ONE launch, the hidden activation staying in LDS; 0 = two launches
- *   "codec_lds_target" [PTTS_CODEC_LDS_TARGET, 45056]  the codec's GEMM launches pad their LDS request to this many bytes
+ *   "codec_lds_target" [PTTS_CODEC_LDS_TARGET, 57344]  the codec's GEMM launches pad their LDS request to this many bytes
  *                                           per workgroup (0 = off): fewer codec workgroups per CU, so the FlowLM stream's
- *                                           short dependent kernels find free wave slots (+2 % pipelined throughput)
+ *                                           short dependent kernels find free wave slots and registers (+5 % pipelined throughput at batch 64)
  *   "flow_max_cus"  [-, 128]                resident workgroups of the cooperative flow launch (8..256): at most the number
  *                                           of CUs its stream may use (a CU-masked FlowLM stream needs it lowered)
  * Applies to steps enqueued / graphs captured after the call.  Returns -1 for an unknown key. */

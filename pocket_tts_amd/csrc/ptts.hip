@@ -126,7 +126,7 @@ struct ptts_engine {
   LmLayerP *lm_table = nullptr;  // device table of the FlowLM layers for lm_cluster_kernel (null: not eligible)
   int opt_k_rotate = 0;
   long fuse_res_min_rows = 0;
-  int opt_codec_lds_target = 44 * 1024;  // see lds_pad()
+  int opt_codec_lds_target = 56 * 1024;  // see lds_pad()
   int opt_fuse_res = 1;  // SEANet residual blocks of stages 2 and 3 as one launch each (gemm_lds_kernel<.., NT2>)
   int opt_flow_max_cus = 128;  // resident workgroups of the single-launch flow MLP (<= the CUs its stream may use)
   std::recursive_mutex mu;  // entry points that enqueue work or touch tuner / profiler / LSD tables hold it
@@ -414,13 +414,14 @@ static void launch_cfg_q8(hipStream_t st, const GemmArgs &a, int pre) {
   else gemm_kernel<TN, TM, WK, WN, WM, PRE_NONE, true><<<grid, block, 0, st>>>(a);
 }
 
-// Occupancy cap of the codec's GEMM launches (engine option "codec_lds_target", bytes; 0 = off): they request dynamic LDS
-// up to this total per workgroup, which limits their workgroups per CU to 160 KB / target and leaves wave slots and
-// registers for the FlowLM stream's kernels, whose dependent chain is what the pipelined step waits for.  Measured at
-// batch 64 (tools/ab_env.sh PTTS_CODEC_LDS_TARGET): 0 -> 0.936 ms per step, 44 KB (3 per CU) -> 0.917, 56 KB (2 per CU)
-// -> 0.917; the codec graph alone 0.548 -> 0.554 -> 0.589 ms (tools/ov_ldspad.sh).
+// Occupancy cap of the codec's GEMM launches (engine option "codec_lds_target", bytes <= 64 KB; 0 = off): they request
+// dynamic LDS up to this total per workgroup, which limits their workgroups per CU to 160 KB / target and leaves wave slots
+// and registers for the FlowLM stream's kernels, whose dependent chain is what the pipelined step waits for.  Measured at
+// batch 64 (tools/ab_env.sh PTTS_CODEC_LDS_TARGET, final kernels): 0 -> 0.893 ms per step, 36 KB (4 per CU) -> 0.882,
+// 44 KB (3) -> 0.864, 56 KB (2) -> 0.851; the codec graph alone 0.548 -> 0.554 (44 KB) -> 0.589 ms (56 KB).
 static thread_local int g_lds_target = 0;
 static unsigned lds_pad(int static_bytes) { return g_lds_target > static_bytes ? (unsigned)(g_lds_target - static_bytes) : 0u; }
+#define LDS_LAUNCH(kernel, grid, block, dyn, st, arg) (kernel)<<<(grid), (block), (dyn), (st)>>>(arg)
 
 template <int TN, int TM, int WK, int WN, int WM>
 static void launch_cfg(hipStream_t st, const GemmArgs &a, int pre) {
@@ -428,10 +429,10 @@ static void launch_cfg(hipStream_t st, const GemmArgs &a, int pre) {
   dim3 block(64 * WK * WN * WM);
   const unsigned dyn = lds_pad(WK > 1 ? WK * WN * WM * TN * TM * 1024 : 0);
   switch (pre) {
-    case PRE_NONE: gemm_kernel<TN, TM, WK, WN, WM, PRE_NONE><<<grid, block, dyn, st>>>(a); break;
-    case PRE_LNFOLD: gemm_kernel<TN, TM, WK, WN, WM, PRE_LNFOLD><<<grid, block, dyn, st>>>(a); break;
-    case PRE_LNMOD: gemm_kernel<TN, TM, WK, WN, WM, PRE_LNMOD><<<grid, block, dyn, st>>>(a); break;
-    default: gemm_kernel<TN, TM, WK, WN, WM, PRE_ADDSILU><<<grid, block, dyn, st>>>(a); break;
+    case PRE_NONE: LDS_LAUNCH((gemm_kernel<TN, TM, WK, WN, WM, PRE_NONE>), grid, block, dyn, st, a); break;
+    case PRE_LNFOLD: LDS_LAUNCH((gemm_kernel<TN, TM, WK, WN, WM, PRE_LNFOLD>), grid, block, dyn, st, a); break;
+    case PRE_LNMOD: LDS_LAUNCH((gemm_kernel<TN, TM, WK, WN, WM, PRE_LNMOD>), grid, block, dyn, st, a); break;
+    default: LDS_LAUNCH((gemm_kernel<TN, TM, WK, WN, WM, PRE_ADDSILU>), grid, block, dyn, st, a); break;
   }
 }
 
@@ -439,8 +440,8 @@ template <int BMT, int BNT>
 static void launch_lds(hipStream_t st, const GemmArgs &a, int pre) {
   dim3 grid(cdiv(a.NT, BNT), cdiv(a.MT, BMT));
   const unsigned dyn = lds_pad(2 * (BMT + BNT) * 2 * 1024);
-  if (pre == PRE_LNFOLD) gemm_lds_kernel<BMT, BNT, 2, PRE_LNFOLD><<<grid, 256, dyn, st>>>(a);
-  else gemm_lds_kernel<BMT, BNT, 2, PRE_NONE><<<grid, 256, dyn, st>>>(a);
+  if (pre == PRE_LNFOLD) LDS_LAUNCH((gemm_lds_kernel<BMT, BNT, 2, PRE_LNFOLD>), grid, dim3(256), dyn, st, a);
+  else LDS_LAUNCH((gemm_lds_kernel<BMT, BNT, 2, PRE_NONE>), grid, dim3(256), dyn, st, a);
 }
 
 // Tile selection.  K-split configs (TM row tiles per wave, 4 waves split K, LDS-reduced) give NT x ceil(MT/TM)
@@ -679,8 +680,8 @@ static void launch_resblock(hipStream_t st, GemmArgs a, const Lin &Bl) {
   ProfScope ps(st, std::string(a.NT == 2 ? "resblock<2,4>" : "resblock<4,8>") + "@" + std::to_string((long)cdiv(a.MT, 4) * 256),
                4.0 * (N * K + N2 * N + M * a.CF * 16.0 + 2.0 * M * N2), 2.0 * M * N * K + 2.0 * M * N2 * N);
   dim3 grid(1, cdiv(a.MT, 4));
-  if (a.NT == 2) gemm_lds_kernel<4, 2, 2, PRE_NONE, 2, 4><<<grid, 256, lds_pad(24 * 1024), st>>>(a);
-  else gemm_lds_kernel<4, 4, 2, PRE_NONE, 2, 8><<<grid, 256, lds_pad(32 * 1024), st>>>(a);
+  if (a.NT == 2) LDS_LAUNCH((gemm_lds_kernel<4, 2, 2, PRE_NONE, 2, 4>), grid, dim3(256), lds_pad(24 * 1024), st, a);
+  else LDS_LAUNCH((gemm_lds_kernel<4, 4, 2, PRE_NONE, 2, 8>), grid, dim3(256), lds_pad(32 * 1024), st, a);
 }
 
 static void bind_engine(ptts_engine *e) {
