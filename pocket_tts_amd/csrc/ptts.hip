@@ -439,6 +439,24 @@ static void launch_cfg(hipStream_t st, const GemmArgs &a, int pre) {
 template <int BMT, int BNT>
 static void launch_lds(hipStream_t st, const GemmArgs &a, int pre) {
   dim3 grid(cdiv(a.NT, BNT), cdiv(a.MT, BMT));
+  // Under the occupancy cap the padded LDS is free, so the capped launches run a THREE-stage ring (two stages in flight
+  // with two workgroups per CU): 0.862 -> 0.857 ms per pipelined step; four k-fragments per stage instead: 0.909
+  // (tools/ab_env.sh PTTS_LDS_VARIANT 0 / 1 / 2).  Uncapped launches keep two stages (never slower, round 1).
+  static const int variant = [] { const char *v = getenv("PTTS_LDS_VARIANT"); return v ? atoi(v) : 1; }();
+  if constexpr (BMT == 4 && BNT <= 4) {
+    if (variant == 1 && g_lds_target) {
+      const unsigned dyn3 = lds_pad(3 * (BMT + BNT) * 2 * 1024);
+      if (pre == PRE_LNFOLD) gemm_lds_kernel<BMT, BNT, 2, PRE_LNFOLD, 3><<<grid, 256, dyn3, st>>>(a);
+      else gemm_lds_kernel<BMT, BNT, 2, PRE_NONE, 3><<<grid, 256, dyn3, st>>>(a);
+      return;
+    }
+    if (variant == 2 && g_lds_target && a.KF % 4 == 0) {
+      const unsigned dyn4 = lds_pad(2 * (BMT + BNT) * 4 * 1024);
+      if (pre == PRE_LNFOLD) gemm_lds_kernel<BMT, BNT, 4, PRE_LNFOLD><<<grid, 256, dyn4, st>>>(a);
+      else gemm_lds_kernel<BMT, BNT, 4, PRE_NONE><<<grid, 256, dyn4, st>>>(a);
+      return;
+    }
+  }
   const unsigned dyn = lds_pad(2 * (BMT + BNT) * 2 * 1024);
   if (pre == PRE_LNFOLD) LDS_LAUNCH((gemm_lds_kernel<BMT, BNT, 2, PRE_LNFOLD>), grid, dim3(256), dyn, st, a);
   else LDS_LAUNCH((gemm_lds_kernel<BMT, BNT, 2, PRE_NONE>), grid, dim3(256), dyn, st, a);
@@ -753,8 +771,12 @@ static int attn_splits(int base, int max_tiles) {
 static void launch_attn(hipStream_t st, const AttnArgs &at, int BH) {
   const dim3 grid(BH, at.QB, at.splits);
   const int nw = attn_nw(BH * at.QB);
+  // large launches (one wave per workgroup) keep two register tiles instead of three: 32 registers less per wave, 0.854 ->
+  // 0.850 ms per pipelined step at batch 64 (tools/ab_env.sh PTTS_ATTN_DEPTH)
+  static const int depth = [] { const char *v = getenv("PTTS_ATTN_DEPTH"); return v ? atoi(v) : 2; }();  // A/B knob
   if (nw == 4) attn_kernel<4><<<grid, 256, 0, st>>>(at);
   else if (nw == 2) attn_kernel<2><<<grid, 128, 0, st>>>(at);
+  else if (depth == 2) attn_kernel<1, 2><<<grid, 64, 0, st>>>(at);
   else attn_kernel<1><<<grid, 64, 0, st>>>(at);
 }
 

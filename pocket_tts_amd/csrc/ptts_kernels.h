@@ -1407,7 +1407,7 @@ __device__ __forceinline__ void attn_store_out(const AttnArgs &a, int b, int h, 
 //   O^T = V^T P^T: A = V[key 4g + r'][4 i + j] (the lane's own 16-byte V load), B = p[r'] -> lane (c, g) accumulates
 //                  O[query c][16 g + 4 rr + j]: the online-softmax rescale and the final 1/l are per-LANE scalars,
 //                  and the only cross-lane traffic of a tile is one max and one sum over the four rows (xrow_*).
-template <int NW>
+template <int NW, int D = 3>
 __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
   if constexpr (PTTS_ABLATE & 128) return;
   const int bh = blockIdx.x, qb = blockIdx.y, sp = blockIdx.z;
@@ -1495,31 +1495,30 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
       o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf4[r].w, p[r], o[3], 0, 0, 0);
     }
   };
-  // Three rotating register tiles: the K/V of the next TWO key tiles (16 KB per wave) are in flight while a tile's
-  // scores, softmax and P.V run.  A decode step streams the whole cache once with ~4 waves per CU, so bytes in
-  // flight per wave are what sets the achieved HBM rate.
+  // D rotating register tiles: the K/V of the next D - 1 key tiles (8 KB each) are in flight while a tile's scores,
+  // softmax and P.V run (D = 3 alone; D = 2 costs 32 registers less per wave, which matters beside the other stream).
   // The prefetches are UNCONDITIONAL (tile index clamped to the last tile, whose lines are then L1/L2 hits): a
   // load behind a branch makes the compiler's s_waitcnt insertion merge the two paths conservatively and wait for
   // the newest loads as well, which silently serialises the whole pipeline (seen in the ISA: vmcnt(5)..vmcnt(0)
   // in front of the first MFMAs of a tile).
-  f32x4 k0[4], v0[4], k1[4], v1[4], k2[4], v2[4];
+  f32x4 kt[D][4], vt[D][4];
   if (ts < te) {
     const int tl = te - 1;
-    load_tile(ts, k0, v0);
-    load_tile(min(ts + 1, tl), k1, v1);
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) load_tile(min(ts + j, tl), kt[j], vt[j]);
     int tile = ts;
-    // whole groups of three tiles: one back-edge, no exits from inside the body (every extra control-flow join
+    // whole groups of D tiles: one back-edge, no exits from inside the body (every extra control-flow join
     // makes the wait counts more conservative)
-    for (; tile + 3 <= te; tile += 3) {
-      load_tile(min(tile + 2, tl), k2, v2);
-      process(tile, k0, v0);
-      load_tile(min(tile + 3, tl), k0, v0);
-      process(tile + 1, k1, v1);
-      load_tile(min(tile + 4, tl), k1, v1);
-      process(tile + 2, k2, v2);
+    for (; tile + D <= te; tile += D) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        load_tile(min(tile + j + D - 1, tl), kt[(j + D - 1) % D], vt[(j + D - 1) % D]);
+        process(tile + j, kt[j], vt[j]);
+      }
     }
-    if (tile < te) process(tile, k0, v0);
-    if (tile + 1 < te) process(tile + 1, k1, v1);
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j)
+      if (tile + j < te) process(tile + j, kt[j], vt[j]);
   }
   if constexpr (NW > 1) {
     // a wave without tiles has m = NEG_BIG, l = 0, o = 0 and weight exp(NEG_BIG - M) = 0
