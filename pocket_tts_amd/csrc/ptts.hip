@@ -1910,8 +1910,9 @@ extern "C" int ptts_mimi_set_pcm_i16(ptts_mimi_state *s, int16_t *d_pcm_i16) {
 template <int TN, int TM, int WN, int WM>
 static void launch_h_cfg(hipStream_t st, const GemmArgs &a, int pre) {
   const dim3 grid(cdiv(a.NT, TN * WN), cdiv(a.MT, TM * WM)), block(64 * WN * WM);
-  if (pre == PRE_LNFOLD) gemm_h_kernel<TN, TM, WN, WM, PRE_LNFOLD><<<grid, block, 0, st>>>(a);
-  else gemm_h_kernel<TN, TM, WN, WM, PRE_NONE><<<grid, block, 0, st>>>(a);
+  const unsigned dyn = lds_pad(0);  // occupancy cap of the codec stream (the kernel itself uses no LDS)
+  if (pre == PRE_LNFOLD) gemm_h_kernel<TN, TM, WN, WM, PRE_LNFOLD><<<grid, block, dyn, st>>>(a);
+  else gemm_h_kernel<TN, TM, WN, WM, PRE_NONE><<<grid, block, dyn, st>>>(a);
 }
 static void launch_gemm_h(hipStream_t st, const GemmArgs &a_in, int pre, const Lin &L) {
   GemmArgs a = a_in;
@@ -1947,6 +1948,7 @@ static void launch_gemm_h(hipStream_t st, const GemmArgs &a_in, int pre, const L
 static int mimi_enqueue_h(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, const float *d_latent, float *d_pcm) {
   const ptts_config &c = e->cfg;
   bind_engine(e);
+  struct LdsScope { LdsScope(int t) { g_lds_target = t; } ~LdsScope() { g_lds_target = 0; } } lds_scope(e->opt_codec_lds_target);
   const int B = s->B, C = c.m_dim, CB = C / 32, st16 = c.upsample_stride;
   SITE("mimi.prologue");
   {

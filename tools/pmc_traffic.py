@@ -19,9 +19,13 @@ def norm(name):
     if m:
         a = [int(x) for x in m.groups()[:6]]
         return "gemm<%d,%d,%d,%d,%d>%s%s" % (*a[:5], PRE.get(a[5], ""), "+q8" if m.group(7) == "true" else "")
-    m = re.search(r"gemm_lds_kernel<(\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>", name)
+    m = re.search(r"gemm_lds_kernel<(\d+), (\d+), (\d+), (\d+)(?:, (\d+))?(?:, (\d+))?>", name)
     if m:
+        if m.group(6) and int(m.group(6)) > 0:  # fused residual block: bench.py's profiler calls it resblock<BNT,NT2>
+            return "resblock<%s,%s>" % (m.group(2), m.group(6))
         return "gemm_lds<%s,%s,%s>%s" % (m.group(1), m.group(2), m.group(3), PRE.get(int(m.group(4)), ""))
+    if "attn_decode" in name:
+        return "attn_decode"
     m = re.search(r"gemm_h_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>", name)
     if m:
         return "gemm_h<%s,%s,%s,%s>%s" % (*m.groups()[:4], "+ln" if m.group(5) == "3" else "")
