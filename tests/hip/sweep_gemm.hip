@@ -11,6 +11,7 @@
 #include <vector>
 static int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static float *g_buf; static hipStream_t g_st;
+static int g_lds_target = 0;  // total LDS bytes per workgroup requested (occupancy cap experiment), 0 = none
 struct Res { std::string cfg; double us; int gx, gy; };
 template <int TN, int TM, int WK, int WN, int WM>
 static void run(std::vector<Res> &out, int M, int N, int K, int ntaps, int T) {
@@ -24,7 +25,9 @@ static void run(std::vector<Res> &out, int M, int N, int K, int ntaps, int T) {
   a.par = ntaps > 1 ? (int *)(g_buf + wsz + 2 * xsz + ysz) : nullptr;
   a.NT = NT; a.KF = KF; a.CF = CF; a.ntaps = ntaps; a.XF = CF; a.MT = MT; a.M = M; a.T = T; a.epi = EPI_STORE; a.YF = NT; a.xstride = 1; a.halo = ntaps - 1;
   dim3 grid(cdiv(NT, TN * WN), cdiv(MT, TM * WM));
-  auto launch = [&] { gemm_kernel<TN, TM, WK, WN, WM, PRE_NONE><<<grid, 64 * WK * WN * WM, 0, g_st>>>(a); };
+  const int st_lds = WK > 1 ? WK * WN * WM * TN * TM * 1024 : 0;
+  const unsigned dyn = g_lds_target > st_lds ? g_lds_target - st_lds : 0;
+  auto launch = [&] { gemm_kernel<TN, TM, WK, WN, WM, PRE_NONE><<<grid, 64 * WK * WN * WM, dyn, g_st>>>(a); };
   for (int i = 0; i < 3; ++i) launch();
   hipStreamSynchronize(g_st);
   const int R = 20;
@@ -46,7 +49,9 @@ static void run_lds(std::vector<Res> &out, int M, int N, int K, int ntaps, int T
   a.par = ntaps > 1 ? (int *)(g_buf + wsz + 2 * xsz + ysz) : nullptr;
   a.NT = NT; a.KF = KF; a.CF = CF; a.ntaps = ntaps; a.XF = CF; a.MT = MT; a.M = M; a.T = T; a.epi = EPI_STORE; a.YF = NT; a.xstride = 1; a.halo = ntaps - 1;
   dim3 grid(cdiv(NT, BNT), cdiv(MT, BMT));
-  auto launch = [&] { gemm_lds_kernel<BMT, BNT, KC, PRE_NONE><<<grid, 256, 0, g_st>>>(a); };
+  const int st_lds = 2 * (BMT + BNT) * KC * 1024;
+  const unsigned dyn = g_lds_target > st_lds ? g_lds_target - st_lds : 0;
+  auto launch = [&] { gemm_lds_kernel<BMT, BNT, KC, PRE_NONE><<<grid, 256, dyn, g_st>>>(a); };
   for (int i = 0; i < 3; ++i) launch();
   hipStreamSynchronize(g_st);
   const int R = 20;
@@ -102,6 +107,7 @@ static void sweep(const char *name, int M, int N, int K, int ntaps, int T) {
 int main(int argc, char **argv) {
   hipStreamCreate(&g_st);
   hipMalloc(&g_buf, (size_t)3 << 30); hipMemset(g_buf, 0, (size_t)3 << 30);
+  if (argc > 2) g_lds_target = atoi(argv[2]);
   if (argc > 1 && !strcmp(argv[1], "pmc")) {  // a handful of (shape, tile) pairs for a rocprofv3 --pmc pass
     std::vector<Res> r;
     const int R = 1024;
@@ -110,6 +116,9 @@ int main(int argc, char **argv) {
     run<2, 4, 4, 1, 1>(r, R, 512, 512, 7, 16);       // seanet.conv0
     run_lds<4, 4, 2>(r, 30 * R, 64, 128, 3, 480);    // seanet.res2a
     run_lds<8, 8, 2>(r, 30 * R, 256, 128, 2, 480);   // convtr3 on the large tile
+    run_lds<4, 4, 2>(r, 30 * R, 256, 128, 2, 480);   // convtr3 on the tile the pipeline uses
+    run_lds<4, 2, 2>(r, R, 1536, 512, 2, 16);        // seanet.convtr1
+    run_lds<4, 8, 2>(r, 6 * R, 640, 256, 2, 96);     // seanet.convtr2
     for (auto &x : r) printf("%s %.1f us (%dx%d)\n", x.cfg.c_str(), x.us, x.gx, x.gy);
     return 0;
   }
