@@ -40,7 +40,7 @@ def collect(d, counter):
             if r["Counter_Name"] != counter:
                 continue
             name = norm(r["Kernel_Name"])
-            if name.startswith(("gemm", "attn", "flow_cluster", "lm_cluster")) and not name.startswith("attn_combine"):
+            if name.startswith(("gemm", "attn", "flow_cluster", "lm_cluster", "resblock")) and not name.startswith("attn_combine"):
                 name += "@" + r["Grid_Size"]  # as bench.py's profiler labels them: one label = one grid = one shape class
             a = acc[name]
             a[0] += 1
