@@ -2577,8 +2577,12 @@ extern "C" int ptts_streams_overlap(ptts_engine *e, void *stream_a, void *stream
   HIPCHK(hipSetDevice(e->device));
   hipStream_t a = S(e, stream_a), b = S(e, stream_b);
   if (a == b) return 0;
-  hipEvent_t e0, e1, e2;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
+  struct Events {  // destroyed on every exit path
+    hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+    ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+  } ev;
+  for (hipEvent_t &x : ev.e) HIPCHK(hipEventCreate(&x));
+  hipEvent_t e0 = ev.e[0], e1 = ev.e[1], e2 = ev.e[2];
   HIPCHK(hipStreamSynchronize(a)); HIPCHK(hipStreamSynchronize(b));
   float worst = 0.f;
   for (int rep = 0; rep < 2; ++rep) {  // first round also warms the kernel up
@@ -2594,7 +2598,6 @@ extern "C" int ptts_streams_overlap(ptts_engine *e, void *stream_a, void *stream
     HIPCHK(hipEventElapsedTime(&t2, e0, e2));
     worst = std::max(t1, t2);
   }
-  hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
   return worst < 0.33f ? 1 : 0;  // 0.2 ms each: ~0.21 overlapped, ~0.41 serialised
 }
 extern "C" int ptts_stream_destroy(void *stream) {

@@ -60,6 +60,8 @@ def build_parser() -> argparse.ArgumentParser:
     g.add_argument("--device", default="cuda:0")
     g.add_argument("--max-tokens", type=int, default=50)
     g.add_argument("--quantize", action="store_true")
+    g.add_argument("--codec-bf16", action="store_true",
+                   help="bf16 weights + activations in the Mimi codec (fp32 accumulate; not in the reference, ~44 dB SNR)")
     return ap
 
 
@@ -76,7 +78,8 @@ def cli_app(argv=None) -> int:
 
     model = TTSModel.load_model(language=args.language, config=args.config, temp=args.temperature,
                                 lsd_decode_steps=args.lsd_decode_steps, noise_clamp=args.noise_clamp,
-                                eos_threshold=args.eos_threshold, quantize=args.quantize, device=args.device)
+                                eos_threshold=args.eos_threshold, quantize=args.quantize, codec_bf16=args.codec_bf16,
+                                device=args.device)
     voice = args.voice if args.voice is not None else "alba"
     state = model.get_state_for_audio_prompt(voice)
     chunks = model.generate_audio_stream(state, text, frames_after_eos=args.frames_after_eos, max_tokens=args.max_tokens)

@@ -412,6 +412,8 @@ class TTSModel:
         finally:
             pipe.sync()
             self._ctx_cache[key] = ctx
+        if st.error():  # a cooperative kernel gave up waiting for a peer (GPU oversubscribed beyond the library's contract)
+            raise RuntimeError("libptts: a cooperative FlowLM kernel timed out; the audio of this chunk is invalid")
         dur_ms = int(total * 1000 / self.config.mimi.sample_rate)
         gen_ms = max(1, int((time.monotonic() - t_start) * 1000))
         logger.info("Generated: %d ms of audio in %d ms so %.2fx faster than real-time", dur_ms, gen_ms, dur_ms / gen_ms)
