@@ -264,12 +264,20 @@ def pmc_traffic(name, table_id):
         return None
 
 
-def roofline_of(per_kernel, table_id):
-    name, k = max(per_kernel.items(), key=lambda kv: kv[1]["total_ms"])
+def roofline_of(rows, table_id):
+    """The dominant kernel = the (launch site, kernel) pair with the largest total time: one site is one operand shape,
+    so bytes / flops per launch are those of ONE GEMM or attention shape (a kernel label alone can cover several shapes,
+    e.g. out_proj and linear2 of the FlowLM share a tile configuration and a grid)."""
+    per_site = {}
+    for r in rows:
+        k = per_site.setdefault((r["site"], r["kernel"]), dict(count=0, total_ms=0.0, bytes=0.0, flops=0.0))
+        for f in ("count", "total_ms", "bytes", "flops"):
+            k[f] += r[f]
+    (site, name), k = max(per_site.items(), key=lambda kv: kv[1]["total_ms"])
     avg_s = k["total_ms"] / k["count"] * 1e-3
     gbs = k["bytes"] / k["count"] / avg_s / 1e9
     tfs = k["flops"] / k["count"] / avg_s / 1e12
-    common = dict(kernel=name, traffic=pmc_traffic(name, table_id), avg_us=avg_s * 1e6, launches=k["count"],
+    common = dict(kernel=name, site=site, traffic=pmc_traffic(name, table_id), avg_us=avg_s * 1e6, launches=k["count"],
                   algorithmic_bytes_per_launch=k["bytes"] / k["count"], flops_per_launch=k["flops"] / k["count"],
                   timing="HIP events around each launch on its own stream (eager steps at mid-utterance context)")
     if tfs / MFMA_F32_PEAK_TF > gbs / HBM_PEAK_GBS:
@@ -509,7 +517,7 @@ def main():
         if not args.no_profile:
             rows, per_kernel, nst, pctx = kernel_profile(eng, job)
             tid = out["tune_table_id"]
-            out["roofline"] = roofline_of(per_kernel, tid)
+            out["roofline"] = roofline_of(rows, tid)
             out["roofline"]["context_keys"] = pctx
             tot = sum(r["total_ms"] for r in rows)
             out["kernel_ms_per_step"] = {k: round(v["total_ms"] / nst, 4) for k, v in
