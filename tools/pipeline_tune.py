@@ -4,7 +4,7 @@ wants (smaller grids leave wave slots to the other stream, larger ones finish so
 isolated-tuned table and does one pass of coordinate descent over the GEMM shapes of one batch size, judging every
 alternative tile by the measured time of whole pipelined utterances (graphs re-captured per trial).
 
-python tools/pipeline_tune.py [batch] [out_file] [config]   (run on the GPU box; prints the changed table lines)"""
+python tools/pipeline_tune.py [batch] [out_file] [config] [int8]   (run on the GPU box; prints the changed table lines)"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -16,7 +16,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 out = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/tune_pipeline.txt"
 NCFG = 16
 cfg = named_config(sys.argv[3] if len(sys.argv) > 3 else "en100m")
-eng = Engine(cfg, generate_state_dict(cfg, 0), "cuda:0")
+groups = {"attention", "ffn"} if len(sys.argv) > 4 and sys.argv[4] == "int8" else None
+eng = Engine(cfg, generate_state_dict(cfg, 0), "cuda:0", quantize_groups=groups)
 args = bench.parse([]); args.batch = B
 job = bench.Job(eng, B, args, 0)
 frames = args.frames
