@@ -484,16 +484,16 @@ static int pick_cfg(const GemmArgs &a) {
   while (tm > 1 && (long)a.NT * cdiv(a.MT, tm) < 256) tm >>= 1;
   return tm == 4 ? 2 : tm == 2 ? 1 : 0;
 }
-static constexpr int kNumCfg = 16;
+static constexpr int kNumCfg = 18;  // 16, 17 appended in round 2 (older cache files stay valid)
 static const char *const kCfgName[kNumCfg] = {
     "gemm<1,1,8,1,1>", "gemm<1,2,4,1,1>", "gemm<1,4,4,1,1>", "gemm<2,4,1,2,2>", "gemm<2,4,1,1,4>", "gemm<1,4,1,1,4>",
     "gemm<1,1,1,1,4>", "gemm<2,4,4,1,1>", "gemm_lds<4,8,2>", "gemm_lds<4,4,2>", "gemm<2,2,4,1,1>", "gemm<1,1,4,1,1>",
-    "gemm_lds<4,2,2>", "gemm<1,2,1,2,2>", "gemm<2,4,2,2,1>", "gemm_lds<8,8,2>"};
+    "gemm_lds<4,2,2>", "gemm<1,2,1,2,2>", "gemm<2,4,2,2,1>", "gemm_lds<8,8,2>", "gemm_lds<8,4,2>", "gemm_lds<8,2,2>"};
 // {TN, TM, WK, WN, WM} of the register-staged configs, {BNT, BMT, 0, 0, 0} of the LDS-staged ones
 static const int kCfgShape[kNumCfg][5] = {{1, 1, 8, 1, 1}, {1, 2, 4, 1, 1}, {1, 4, 4, 1, 1}, {2, 4, 1, 2, 2}, {2, 4, 1, 1, 4},
                                           {1, 4, 1, 1, 4}, {1, 1, 1, 1, 4}, {2, 4, 4, 1, 1}, {8, 4, 0, 0, 0}, {4, 4, 0, 0, 0},
                                           {2, 2, 4, 1, 1}, {1, 1, 4, 1, 1}, {2, 4, 0, 0, 0}, {1, 2, 1, 2, 2}, {2, 4, 2, 2, 1},
-                                          {8, 8, 0, 0, 0}};
+                                          {8, 8, 0, 0, 0}, {4, 8, 0, 0, 0}, {2, 8, 0, 0, 0}};
 
 static bool q8_cfg(int cfg) { return cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 7 || cfg == 10 || cfg == 11; }
 
@@ -556,6 +556,8 @@ static void launch_by_cfg(hipStream_t st, const GemmArgs &a_in, int pre, int cfg
     case 12: launch_lds<4, 2>(st, a, pre); break;
     case 13: launch_cfg<1, 2, 1, 2, 2>(st, a, pre); break;
     case 14: launch_cfg<2, 4, 2, 2, 1>(st, a, pre); break;
+    case 16: launch_lds<8, 4>(st, a, pre); break;
+    case 17: launch_lds<8, 2>(st, a, pre); break;
     default: launch_lds<8, 8>(st, a, pre); break;
   }
 }

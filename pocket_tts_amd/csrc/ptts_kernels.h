@@ -458,11 +458,17 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
   // 0.905-0.910, DIV 4 (128) 0.920.  A FlowLM GEMM is ~1 wave per SIMD that mostly waits for its weights: at 253
   // registers it pins HALF of every SIMD's register file while resident and evicts the codec stream's waves; with half
   // the fragments in flight it is barely slower alone (batch 1: 0.358 -> 0.355 ms per step) and the codec keeps its occupancy.
+  // The optimum is sharp and the same for every tile: the single-tile (1x1) configurations alone at 4 or at 1: 0.875 / 0.878
+  // against 0.846 (PTTS_KSPLIT_DIV1, tools/ab_libs.sh).
 #ifndef PTTS_KSPLIT_DIV
 #define PTTS_KSPLIT_DIV 2
 #endif
   constexpr int U00 = (TN * TM == 1) ? 8 : (TN * TM == 2 && WK > 1) ? 8 : (TN * TM <= 4 && WK > 1) ? 4 : 2;
-  constexpr int U0 = (WK > 1) ? (U00 / PTTS_KSPLIT_DIV >= 1 ? U00 / PTTS_KSPLIT_DIV : 1) : U00;
+#ifndef PTTS_KSPLIT_DIV1
+#define PTTS_KSPLIT_DIV1 PTTS_KSPLIT_DIV  // divisor for the single-tile (1x1) K-split configurations
+#endif
+  constexpr int KDIV = (TN * TM == 1) ? PTTS_KSPLIT_DIV1 : PTTS_KSPLIT_DIV;
+  constexpr int U0 = (WK > 1) ? (U00 / KDIV >= 1 ? U00 / KDIV : 1) : U00;
   constexpr int U = (Q8 && U0 < 4) ? 4 : U0;  // int8 weights arrive four k-fragments per load
   auto load_chunk = [&](auto uc, int kf, f32x4 (*w)[TN], f32x4 (*x)[TM]) {
     constexpr int UU = decltype(uc)::value;

@@ -14,7 +14,7 @@ from pocket_tts_amd.engine import Engine, StepPipeline
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 out = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/tune_pipeline.txt"
-NCFG = 16
+NCFG = 18
 cfg = named_config(sys.argv[3] if len(sys.argv) > 3 else "en100m")
 groups = {"attention", "ffn"} if len(sys.argv) > 4 and sys.argv[4] == "int8" else None
 eng = Engine(cfg, generate_state_dict(cfg, 0), "cuda:0", quantize_groups=groups)
