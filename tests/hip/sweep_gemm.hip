@@ -3,6 +3,7 @@
 // Prints one line per (shape, config) with the time of a back-to-back launch, best config first.
 #include "../../pocket_tts_amd/csrc/ptts_kernels.h"
 #include "exp_lds32.h"
+#include "exp_ldsp.h"
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -62,6 +63,30 @@ static void run_lds(std::vector<Res> &out, int M, int N, int K, int ntaps, int T
   char nm[64]; snprintf(nm, sizeof nm, "LDS<%d,%d,%d>", BMT, BNT, KC);
   out.push_back({nm, us, (int)grid.x, (int)grid.y});
 }
+template <int BMT, int BNT, int NS>
+static void run_ldsp(std::vector<Res> &out, int M, int N, int K, int ntaps, int T) {  // persistent form, 2 workgroups per CU
+  int MT = cdiv(M, 16), NT = cdiv(N, 16), CF = K / 16, KF = CF * ntaps;
+  if (KF % 2 || BMT > 2 * MT || BNT > 2 * NT) return;
+  size_t wsz = (size_t)NT * KF * 256, xsz = (size_t)MT * CF * 256, ysz = (size_t)MT * NT * 256;
+  GemmArgs a; memset(&a, 0, sizeof a);
+  a.W = g_buf; a.X = g_buf + wsz; a.Y = g_buf + wsz + 2 * xsz; a.Xdstride = ntaps > 1 ? xsz : 0;
+  a.par = ntaps > 1 ? (int *)(g_buf + wsz + 2 * xsz + ysz) : nullptr;
+  a.NT = NT; a.KF = KF; a.CF = CF; a.ntaps = ntaps; a.XF = CF; a.MT = MT; a.M = M; a.T = T; a.epi = EPI_STORE; a.YF = NT; a.xstride = 1; a.halo = ntaps - 1;
+  const int tx = cdiv(NT, BNT), ty = cdiv(MT, BMT);
+  const int G = std::min(tx * ty, 512) & ~7;
+  const int st_lds = NS * (BMT + BNT) * 2 * 1024;
+  const unsigned dyn = g_lds_target > st_lds ? g_lds_target - st_lds : 0;
+  auto launch = [&] { gemm_ldsp_kernel<BMT, BNT, 2, PRE_NONE, NS><<<G, 256, dyn, g_st>>>(a, tx, ty); };
+  for (int i = 0; i < 3; ++i) launch();
+  hipStreamSynchronize(g_st);
+  const int R = 20;
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < R; ++i) launch();
+  hipStreamSynchronize(g_st);
+  double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / R;
+  char nm[64]; snprintf(nm, sizeof nm, "LDSP<%d,%d,ns%d>", BMT, BNT, NS);
+  out.push_back({nm, us, G, 1});
+}
 template <int WM, int WN, int KC>
 static void run_lds32(std::vector<Res> &out, int M, int N, int K, int ntaps, int T) {
   constexpr int BMT = 4 * WM, BNT = 4 * WN;
@@ -119,6 +144,11 @@ int main(int argc, char **argv) {
     run_lds<4, 4, 2>(r, 30 * R, 256, 128, 2, 480);   // convtr3 on the tile the pipeline uses
     run_lds<4, 2, 2>(r, R, 1536, 512, 2, 16);        // seanet.convtr1
     run_lds<4, 8, 2>(r, 6 * R, 640, 256, 2, 96);     // seanet.convtr2
+    run_ldsp<4, 4, 3>(r, 30 * R, 256, 128, 2, 480);  // convtr3, persistent
+    run_ldsp<4, 2, 3>(r, 30 * R, 256, 128, 2, 480);
+    run_ldsp<4, 2, 3>(r, R, 1536, 512, 2, 16);       // convtr1, persistent
+    run_ldsp<4, 8, 2>(r, 6 * R, 640, 256, 2, 96);    // convtr2, persistent
+    run_ldsp<4, 4, 3>(r, R, 2048, 512, 1, 16);       // mimi.ff1, persistent
     for (auto &x : r) printf("%s %.1f us (%dx%d)\n", x.cfg.c_str(), x.us, x.gx, x.gy);
     return 0;
   }

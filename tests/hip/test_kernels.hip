@@ -2,7 +2,9 @@
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 -o tests/hip/test_kernels tests/hip/test_kernels.hip && tests/hip/test_kernels
 #include "../../pocket_tts_amd/csrc/ptts_kernels.h"
 #include "exp_lds32.h"
+#include "exp_ldsp.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -54,7 +56,15 @@ static void test_gemm(int M, int N, int K, int cfg) {
   GemmArgs a; memset(&a, 0, sizeof(a));
   a.W = wp; a.bias = bp; a.NT = NT; a.KF = KF; a.CF = KF; a.ntaps = 1; a.X = xfm; a.XF = KF; a.MT = MT; a.M = M; a.T = 16;
   a.epi = EPI_STORE; a.Y = yfm; a.YF = NT;
-  if (cfg == 102 || cfg == 103) {  // 32x32x2 MFMA tiles: workgroup = 64 x 64 (cfg 102) or 128 x 128 (cfg 103)
+  if (cfg >= 104 && cfg <= 106) {  // persistent LDS GEMM: 8 resident workgroups walk all tiles
+    const int bnt = cfg == 104 ? 4 : cfg == 105 ? 2 : 8;
+    const int tx = cdiv(a.NT, bnt), ty = cdiv(a.MT, 4);
+    const int G = std::min(8, tx * ty);
+    if (cfg == 104) gemm_ldsp_kernel<4, 4, 2, PRE_NONE, 3><<<G, 256>>>(a, tx, ty);
+    else if (cfg == 105) gemm_ldsp_kernel<4, 2, 2, PRE_NONE, 3><<<G, 256>>>(a, tx, ty);
+    else gemm_ldsp_kernel<4, 8, 2, PRE_NONE, 2><<<G, 256>>>(a, tx, ty);
+    CK(hipDeviceSynchronize());
+  } else if (cfg == 102 || cfg == 103) {  // 32x32x2 MFMA tiles: workgroup = 64 x 64 (cfg 102) or 128 x 128 (cfg 103)
     const int b16 = cfg == 102 ? 4 : 8;
     dim3 grid(cdiv(a.NT, b16), cdiv(a.MT, b16));
     if (cfg == 102) gemm_lds32_kernel<1, 1, 2><<<grid, 256>>>(a); else gemm_lds32_kernel<2, 2, 2><<<grid, 256>>>(a);
@@ -106,7 +116,14 @@ static void test_conv(int B, int T, int C, int N, int ntaps, int cfg) {
   GemmArgs a; memset(&a, 0, sizeof(a));
   a.W = wp; a.bias = bp; a.NT = NT; a.KF = KF; a.CF = CF; a.ntaps = ntaps; a.X = xfm; a.Xdstride = xs; a.XF = CF; a.MT = MT; a.M = M; a.T = T; a.par = par; a.xstride = 1; a.halo = ntaps - 1;
   a.epi = EPI_STORE; a.Y = yfm; a.YF = NT;
-  if (cfg == 102) {
+  if (cfg == 104 || cfg == 105) {
+    const int bnt = cfg == 104 ? 4 : 2;
+    const int tx = cdiv(a.NT, bnt), ty = cdiv(a.MT, 4);
+    const int G = std::min(8, tx * ty);
+    if (cfg == 104) gemm_ldsp_kernel<4, 4, 2, PRE_NONE, 3><<<G, 256>>>(a, tx, ty);
+    else gemm_ldsp_kernel<4, 2, 2, PRE_NONE, 3><<<G, 256>>>(a, tx, ty);
+    CK(hipDeviceSynchronize());
+  } else if (cfg == 102) {
     dim3 grid(cdiv(a.NT, 4), cdiv(a.MT, 4));
     gemm_lds32_kernel<1, 1, 2><<<grid, 256>>>(a);
   } else if (cfg >= 100) {
@@ -226,6 +243,7 @@ int main() {
   test_gemm(100, 1, 64, 5);
   test_gemm(1, 384, 4096, 0);
   test_gemm(200, 130, 128, 100); test_gemm(300, 200, 512, 101); test_gemm(1024, 64, 64, 100);
+  test_gemm(2000, 130, 128, 104); test_gemm(1500, 200, 512, 105); test_gemm(4096, 64, 64, 104); test_gemm(3000, 300, 96, 106); test_gemm(100, 48, 64, 104);
   test_gemm(200, 130, 128, 102); test_gemm(300, 200, 512, 103); test_gemm(1024, 64, 64, 102); test_gemm(40, 48, 32, 102);
   test_conv(2, 16, 32, 48, 7, 0);
   test_conv(3, 32, 64, 32, 3, 2);
@@ -233,6 +251,7 @@ int main() {
   test_conv(4, 96, 16, 1, 3, 5);
   test_conv(5, 48, 32, 70, 2, 100); test_conv(3, 32, 64, 96, 3, 101); test_conv(9, 16, 32, 64, 7, 100);
   test_conv(5, 48, 32, 70, 2, 102); test_conv(9, 16, 32, 64, 7, 102);
+  test_conv(40, 48, 32, 70, 2, 104); test_conv(30, 32, 64, 96, 3, 105); test_conv(64, 16, 32, 64, 7, 104);
   test_gemm_lnfold(3, 48, 128, 0); test_gemm_lnfold(50, 96, 1024, 2); test_gemm_lnfold(200, 130, 512, 3);
   test_gemm_lnfold(130, 64, 1024, 7);
   test_attn(4, 1, 0, 0, 0, 1);
