@@ -204,8 +204,9 @@ int ptts_tune_import(ptts_engine *e, const char *text);
  *   "codec_lds_target" [PTTS_CODEC_LDS_TARGET, 57344]  the codec's GEMM launches pad their LDS request to this many bytes
  *                                           per workgroup (0 = off): fewer codec workgroups per CU, so the FlowLM stream's
  *                                           short dependent kernels find free wave slots and registers (+5 % pipelined throughput at batch 64)
- *   "flow_max_cus"  [-, 128]                resident workgroups of the cooperative flow launch (8..256): at most the number
- *                                           of CUs its stream may use (a CU-masked FlowLM stream needs it lowered)
+ *   "flow_max_cus"  [PTTS_FLOW_MAX_CUS, 128] resident workgroups of the cooperative flow launch (8..256): at most the number
+ *                                           of CUs its stream may use (a CU-masked FlowLM stream needs it lowered; fewer is
+ *                                           slower in the shared pipeline too: 128 -> 0.852, 64 -> 0.904, 32 -> 1.010 ms per step)
  * Applies to steps enqueued / graphs captured after the call.  Returns -1 for an unknown key. */
 int ptts_set_option(ptts_engine *e, const char *key, int32_t value);
 /* 1 after a cooperative kernel of this state gave up waiting for a peer workgroup (its outputs are then invalid);

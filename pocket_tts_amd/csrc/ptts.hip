@@ -893,6 +893,7 @@ extern "C" int ptts_create_ex(const ptts_config *cfg, const ptts_tensor *tensors
   if (const char *v = getenv("PTTS_LM_CLUSTER")) e->opt_lm_cluster = atoi(v) != 0;
   if (const char *v = getenv("PTTS_K_ROTATE")) e->opt_k_rotate = atoi(v) != 0;
   if (const char *v = getenv("PTTS_FUSE_RES")) e->opt_fuse_res = atoi(v) != 0;
+  if (const char *v = getenv("PTTS_FLOW_MAX_CUS")) e->opt_flow_max_cus = std::max(8, std::min(atoi(v), 256));
   if (const char *v = getenv("PTTS_CODEC_LDS_TARGET")) e->opt_codec_lds_target = std::max(0, std::min(atoi(v), 64 * 1024));
   const int rc = build_engine(e, tensors, n);
   if (rc < 0) {  // missing / ill-shaped tensor, HIP error: release what was built so far
