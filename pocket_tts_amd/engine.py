@@ -520,7 +520,7 @@ class StepPipeline:
         # ring of output buffers (latent -> codec input, EOS flags, PCM).  Throughput mode keeps 4 so that the FlowLM
         # stream may run up to 3 steps ahead of the codec stream (with 2 the two streams move in lock-step and every
         # hiccup of one stalls the other); the latency modes need only 2.
-        self.nb = nb = 4 if self.mode == "events" else 2
+        self.nb = nb = int(os.environ.get("PTTS_PIPE_NB", "4")) if self.mode == "events" else 2
         self.lat = [torch.zeros(B, eng.ldim, device=dev) for _ in range(nb)]
         self.logit = [torch.empty(B, device=dev) for _ in range(nb)]
         self.flag = [torch.zeros(B, dtype=torch.uint8).pin_memory() for _ in range(nb)]  # EOS flags land on the host
