@@ -7,9 +7,18 @@
 A *step* is one 80 ms frame of every utterance of the batch: one FlowLM autoregressive step plus one Mimi codec
 decode for `--batch` (default 64) concurrent fixed-length utterances per GPU (BASELINE.json configs[2]; SURVEY.md
 section 8d).  An *utterance job* is: voice-state clone + text prefill (32 tokens) + 125 steps (10 s of audio).  The
-timed region always STARTS at an utterance boundary, so the clone and the prefill are inside it whatever K is; with the
-default K = 125 it is exactly one whole job.  Inputs (weights, voice KV, token ids) are resident in HBM; every PCM chunk
-lands in pinned host memory inside the timed region.
+timed region consists of WHOLE utterance jobs, whatever `--steps K` is: at least 3 of them, at least ceil(K / 125), and
+enough for >= 1 s of wall time (one untimed job calibrates the count), so the per-utterance costs (clone, prefill,
+pipeline fill and drain) are always amortised over 125 steps each and a 20-step request does not turn into a 20 ms
+measurement.  `steps` in the JSON line is the number of steps actually timed, `ms_per_step` = timed wall / steps, and
+`value` is the MEDIAN per-utterance rate (GPU-timeline events at the utterance boundaries, max over ranks per
+utterance); `value_whole_region` is total audio / total wall.  Inputs (weights, voice KV, token ids) are resident in HBM;
+every PCM chunk lands in pinned host memory inside the timed region.  A cooperative-kernel timeout inside the timed
+region (`ptts_lm_state_error`) makes the run exit non-zero without a JSON line.
+
+`api_batch` in the line (N = 1 only) is the throughput a USER of the drop-in surface gets for 64 concurrent requests:
+`TTSModel.generate_audio_batch` and `ContinuousBatcher` (64 slots), per-row EOS bookkeeping on, every PCM chunk handed to
+the caller, tokenisation, voice clone and prefill inside the timed calls.
 
 `--gpus N` without a launcher starts N fresh worker processes itself (before the parent touches any GPU), one engine
 per GPU, rendezvous on 127.0.0.1; under `torch.distributed.run` the ranks it is given are used.  Utterances are
@@ -69,10 +78,16 @@ def parse(argv=None):
                     help="BASELINE config #5, second half: bf16 Mimi decoder, fp32 accumulate (not the headline)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the cpu_baseline leg")
     ap.add_argument("--latency-trials", type=int, default=200)
+    ap.add_argument("--no-api", action="store_true", help="skip the API-level batch throughput (api_batch)")
+    ap.add_argument("--quick", action="store_true", help="A/B runs: only the timed region (no cpu baseline, latency, API, kernel profile)")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="lower bound of the timed region's wall time")
+    ap.add_argument("--min-utterances", type=int, default=3)
     args = ap.parse_args(argv)
     for k, v in PRESETS[args.preset].items():
         if getattr(args, k) is None:
             setattr(args, k, v)
+    if args.quick:
+        args.no_cpu_baseline = args.no_latency = args.no_api = args.no_profile = True
     args.batch = 64 if args.batch is None else args.batch
     args.config = args.config or "en100m"
     args.quantize = bool(args.quantize)
@@ -146,6 +161,12 @@ class Job:
         if self.frame >= self.args.frames:
             self.pipe.flush()  # the utterances' last frame has no FlowLM step to ride along with
 
+    def run_utterance(self):
+        """one whole utterance job: clone + prefill + `frames` steps (the last frame's codec decode included)"""
+        self.frame = self.args.frames
+        for _ in range(self.args.frames):
+            self.step()
+
     def sync(self):
         self.pipe.sync()
 
@@ -215,6 +236,65 @@ def first_chunk_latency(eng, args, job1):
                 measured_through="TTSModel.generate_audio_stream()", trials=args.latency_trials,
                 engine_level_first_chunk_ms_p50=float(np.percentile(eng_ms, 50)),
                 b1_ms_per_step=per_step_ms, b1_xrt=FRAME_S * 1e3 / per_step_ms)
+
+
+def api_batch_throughput(eng, args, voice_lm_state):
+    """BASELINE config #3 through the API a user calls: 64 requests of 32 tokens against one voice,
+    EOS stop disabled by the threshold (every request runs its `estimate_max_gen_len` = 159 frames, the reference's own
+    bound, tts_model.py:907-910) but the per-row EOS bookkeeping of tts_model.py:756-768 runs on every step; tokenising,
+    voice clone, grouped prefill, the step pipeline and handing every PCM chunk to the caller are inside the timed calls.
+    Median of 3 calls after one warm call each."""
+    import logging
+
+    import numpy as np
+
+    from pocket_tts_amd.batching import ContinuousBatcher
+    from pocket_tts_amd.text import estimate_max_gen_len
+    from pocket_tts_amd.tts_model import TTSModel, _export_lm_state
+
+    logging.getLogger("pocket_tts_amd").setLevel(logging.ERROR)  # "max length without EOS" x 64 per call is expected here
+    cfg, B = eng.cfg, args.batch
+    model = TTSModel(eng, cfg, _CharTokenizer(cfg.flow_lm.lookup_table.n_bins), args.temp, 1, None, float("inf"))
+    voice_state = _export_lm_state(eng, voice_lm_state, args.voice_len)
+    texts = [f"The quick brown fox jumps {i:04d}." for i in range(B)]  # 31 characters + marker = 32 tokens each
+    assert all(len(model.tokenizer.encode(t)) == 32 for t in texts)
+    frames = estimate_max_gen_len(32, cfg.mimi.frame_rate)
+    audio = B * frames * FRAME_S
+    out = dict(requests=B, tokens_per_request=32, frames_per_request=frames,
+               note="EOS threshold +inf: fixed-length requests, bookkeeping on; PCM handed to the caller")
+    ts = []
+    for i in range(4):
+        eng.sync()
+        t0 = time.perf_counter()
+        wavs = model.generate_audio_batch(voice_state, texts)
+        dt = time.perf_counter() - t0
+        assert len(wavs) == B and all(w.shape[0] == frames * eng.frame_samples for w in wavs)
+        if i:
+            ts.append(dt)
+    out["generate_audio_batch_xrt"] = audio / float(np.median(ts))
+    out["generate_audio_batch_ms"] = float(np.median(ts)) * 1e3
+    model._drop_batch_contexts()
+    cb = ContinuousBatcher(model, slots=B, capacity=512)
+    try:
+        ts = []
+        for i in range(4):
+            eng.sync()
+            t0 = time.perf_counter()
+            reqs = [cb.submit(voice_state, t) for t in texts]
+            cb.run_until_idle()
+            n = 0
+            for r in reqs:
+                for chunk in r:  # a server would write each chunk to its client's socket here
+                    n += chunk.shape[0]
+            dt = time.perf_counter() - t0
+            assert n == B * frames * eng.frame_samples, (n, B * frames * eng.frame_samples)
+            if i:
+                ts.append(dt)
+        out["continuous_batcher_xrt"] = audio / float(np.median(ts))
+        out["continuous_batcher_ms"] = float(np.median(ts)) * 1e3
+    finally:
+        cb.close()
+    return out
 
 
 def kernel_profile(eng, job, nsteps=6):
@@ -445,19 +525,42 @@ def main():
     for _ in range(args.warmup):
         job.step()
     job.pipe.flush()
-    job.frame = args.frames  # the timed region starts at an utterance boundary: clone + prefill are inside it
+    # one untimed whole utterance: warms the prefill path and tells how many utterances make >= --min-seconds
+    barrier()
+    tc = time.perf_counter()
+    job.run_utterance()
+    job.sync()
+    t_utt = time.perf_counter() - tc
+    n_utt = max(args.min_utterances, -(-args.steps // args.frames), int(np.ceil(args.min_seconds / max(t_utt, 1e-6))))
+    if dist is not None:  # every rank times the same number of utterances
+        t = torch.tensor([n_utt], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        n_utt = int(t.item())
+    steps_timed = n_utt * args.frames
     job.contexts = []
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_utt + 1)]
     barrier()
     eng.timer_start()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        job.step()
-    job.pipe.flush()
+    marks[0].record(job.pipe.s2)
+    for u in range(n_utt):
+        job.run_utterance()
+        marks[u + 1].record(job.pipe.s2)  # behind the utterance's last codec frame (the codec stream)
     job.sync()
     ev_ms = eng.timer_stop_ms()
     barrier()
     wall_rank = time.perf_counter() - t0
-    audio_rank = args.batch * args.steps * FRAME_S
+    err = torch.tensor([1 if job.st.error() else 0], dtype=torch.int32, device=dev)
+    if dist is not None:
+        dist.all_reduce(err, op=dist.ReduceOp.MAX)
+    if int(err.item()):
+        print("bench.py: a cooperative FlowLM kernel timed out inside the timed region (ptts_lm_state_error): the "
+              "measurement is invalid", file=sys.stderr)
+        if dist is not None:
+            dist.destroy_process_group()
+        sys.exit(3)
+    utt_ms = torch.tensor([marks[u].elapsed_time(marks[u + 1]) for u in range(n_utt)], dtype=torch.float64, device=dev)
+    audio_rank = args.batch * steps_timed * FRAME_S
     rate, wall = parallel.job_throughput(audio_rank, wall_rank, dist, dev)
     per_rank = [audio_rank / wall_rank]
     if dist is not None:
@@ -465,6 +568,9 @@ def main():
         t[rank] = per_rank[0]
         dist.all_reduce(t)
         per_rank = [float(v) for v in t.tolist()]
+        dist.all_reduce(utt_ms, op=dist.ReduceOp.MAX)  # an utterance of the job ends when its slowest rank ends
+    utt_ms = [float(v) for v in utt_ms.tolist()]
+    utt_rates = [world * args.batch * args.frames * FRAME_S / (m * 1e-3) for m in utt_ms]
 
     if rank == 0:
         L = cfg.flow_lm.transformer.num_layers
@@ -472,12 +578,18 @@ def main():
         restarts = sum(1 for c in job.contexts if c == args.voice_len + args.text_len + 1)
         out = {
             "metric": "audio-seconds/sec (xRT), 100M en model, whole job over all GPUs",
-            "value": rate,
+            "value": float(np.median(utt_rates)),
             "unit": "audio-seconds/sec",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps_timed,
+            "steps_requested": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": wall * 1e3 / args.steps,
+            "ms_per_step": wall * 1e3 / steps_timed,
+            "value_whole_region": rate,
+            "utterances_timed": n_utt,
+            "utterance_ms": [round(m, 3) for m in utt_ms],
+            "value_definition": "median over the timed utterances of (GPUs x batch x 10 s) / utterance time; utterance "
+                                "time from HIP events behind each utterance's last codec frame (codec stream), max over ranks",
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -493,12 +605,12 @@ def main():
                 "preset": args.preset,
                 "batch_per_gpu": args.batch,
                 "parallelism": f"replicas x{world} (no collective on the data path)",
-                "timed_region": f"{args.steps} steps from an utterance boundary: {restarts} clone+prefill inside, "
-                                f"mean FlowLM context {ctx:.1f} keys",
+                "timed_region": f"{n_utt} whole utterances = {steps_timed} steps: {restarts} clone+prefill inside, "
+                                f"mean FlowLM context {ctx:.1f} keys, {wall:.3f} s wall",
             },
             "xrt_per_gpu": rate / world,
             "per_rank_xrt": per_rank,
-            "stream_event_ms_per_step": ev_ms / args.steps,
+            "stream_event_ms_per_step": ev_ms / steps_timed,
             "tune_table_id": tune_table_id(eng),
         }
         # whole-step bounds at the contexts actually timed (SURVEY 8d bytes_step / flops formulas)
@@ -506,7 +618,7 @@ def main():
                       + args.batch * (8 * L * ctx * 1024 + 2.18e6 + 68e3))
         lm_mac = eng.lm_weight_bytes() / (1.0 if args.quantize else 4.0)  # one MAC per weight and row (int8: ~1 B/weight)
         flops_step = 2.0 * args.batch * (lm_mac + 2 * L * ctx * 1024 + MIMI_MAC_PER_FRAME)
-        step_s = wall / args.steps
+        step_s = wall / steps_timed
         out["step_roofline"] = {
             "algorithmic_bytes_per_step": bytes_step, "hbm_bound_us_at_8TBs": bytes_step / 8e12 * 1e6,
             "hbm_frac": bytes_step / 8e12 / step_s,
@@ -539,6 +651,9 @@ def main():
             job1 = Job(eng, 1, a1, seed=7)
             out["latency_b1"] = first_chunk_latency(eng, a1, job1)
             job1 = None
+        if not args.no_api and world == 1 and args.preset in ("headline", "b1") and args.config != "24l" and args.batch > 1:
+            out["api_batch"] = api_batch_throughput(eng, args, job.voice)
+            out["api_batch"]["engine_level_xrt"] = out["value"]
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args, cfg, W)
         print(json.dumps(out), flush=True)

@@ -16,9 +16,11 @@
  * scheduler thread and a request thread); device-side ordering between their calls is the caller's business
  * (streams / events).  A state or graph handle is not re-entrant: one thread per ptts_lm_state / ptts_mimi_state /
  * ptts_graph at a time.  Decode steps contain cooperative kernels (the single-launch flow MLP: all its workgroups must
- * be resident together): the library chains such steps per DEVICE with an event (GPU-side order, no host wait), so
- * steps of different states queued on different streams are safe and run one after the other on the GPU.  The one
- * process-wide object is that per-device event (with its mutex).
+ * be resident together).  Such a launch never exceeds the device's CU count or the `flow_max_cus` option, a launch on a
+ * CU-masked stream with fewer CUs than its grid is refused (-1), and the library admits only as many of these steps at a
+ * time per DEVICE as their grids fit the chip together (two for the default 128-workgroup grid): step k waits ON THE GPU
+ * for step k - 2 through a small per-device ring of events (no host wait), so steps of different states queued on
+ * different streams are safe and overlap pairwise.  The one process-wide object is that per-device ring (with its mutex).
  */
 #ifndef PTTS_H_
 #define PTTS_H_
@@ -74,6 +76,18 @@ int ptts_create(const ptts_config *cfg, const ptts_tensor *tensors, int32_t n_te
  * accumulation (v_mfma_f32_16x16x32_bf16) and fp32 epilogue math; attention, the KV ring and the FlowLM stay fp32, so
  * EOS decisions / frame counts are those of the fp32 model.  Quality: tests/test_gpu_bf16.py (SNR vs the fp32 path). */
 #define PTTS_CODEC_BF16 4
+/* fp8 CODEC CONVOLUTIONS (BASELINE.json config #5: "fp8 MFMA codec convs"; no reference counterpart - the reference never
+ * quantises Mimi, docs/quantization.md:67-76 - parity unpinned, judged by SNR and frame-count equality): the SEANet decoder
+ * convolutions (seanet.py:141-180, conv.py:93-163) run on v_mfma_f32_16x16x32_fp8_fp8 with OCP e4m3 weights (one fp32
+ * scale per output channel) and e4m3 activations (one fp32 scale per tensor, fixed at load time from a calibration
+ * frame), fp32 accumulation and epilogue math; the Mimi decoder transformer runs as under PTTS_CODEC_BF16 (bf16), the
+ * FlowLM stays fp32.  Exclusive with PTTS_CODEC_BF16.  Quality: tests/test_gpu_fp8.py. */
+#define PTTS_CODEC_FP8 8
+/* bf16 WEIGHTS for the FlowLM transformer's Linear layers (SURVEY 8(f).4 "bf16 / int8 per-channel LM weights"; same
+ * hook as the int8 groups: quantization.py:91-128): weights rounded to bf16 once at load, activations and accumulation
+ * fp32 (the bf16 image is widened in registers and fed to the fp32 MFMA), half the weight bytes of a decode step.
+ * Exclusive with the int8 groups.  Quality: tests/test_gpu_quant.py. */
+#define PTTS_LM_BF16 16
 int ptts_create_ex(const ptts_config *cfg, const ptts_tensor *tensors, int32_t n_tensors, int32_t device,
                    int32_t quant_flags, ptts_engine **out);
 /* Packed-engine files ("offline packer"): ptts_engine_save writes everything ptts_create[_ex] built on
@@ -103,6 +117,9 @@ int ptts_lm_state_copy(ptts_lm_state *dst, const ptts_lm_state *src, void *strea
  * one with different prompt lengths; every kernel reads per-row offsets, so rows need not be in sync (the
  * reference requires equal offsets across the batch: transformer.py:12-13). */
 int ptts_lm_state_copy_row(ptts_lm_state *dst, int32_t row, const ptts_lm_state *src, void *stream);
+/* the same from row `src_row` of a batch state: a group of utterances with the same voice and text length is prefilled
+ * as ONE batch (one GEMM pass instead of one per utterance) and its rows are then dealt to their slots */
+int ptts_lm_state_copy_row_from(ptts_lm_state *dst, int32_t row, const ptts_lm_state *src, int32_t src_row, void *stream);
 /* offsets of all rows to host (transformer.py:14 `.item()`; synchronises the stream) */
 int ptts_lm_state_offsets(ptts_lm_state *s, int32_t *h_offsets, void *stream);
 
@@ -204,14 +221,17 @@ int ptts_tune_import(ptts_engine *e, const char *text);
  *   "codec_lds_target" [PTTS_CODEC_LDS_TARGET, 57344]  the codec's GEMM launches pad their LDS request to this many bytes
  *                                           per workgroup (0 = off): fewer codec workgroups per CU, so the FlowLM stream's
  *                                           short dependent kernels find free wave slots and registers (+5 % pipelined throughput at batch 64)
- *   "flow_max_cus"  [PTTS_FLOW_MAX_CUS, 128] resident workgroups of the cooperative flow launch (8..256): at most the number
+ *   "flow_max_cus"  [PTTS_FLOW_MAX_CUS, 128] resident workgroups of the cooperative flow launch (8..CUs of the device): at most the number
  *                                           of CUs its stream may use (a CU-masked FlowLM stream needs it lowered; fewer is
  *                                           slower in the shared pipeline too: 128 -> 0.852, 64 -> 0.904, 32 -> 1.010 ms per step)
  * Applies to steps enqueued / graphs captured after the call.  Returns -1 for an unknown key. */
 int ptts_set_option(ptts_engine *e, const char *key, int32_t value);
-/* 1 after a cooperative kernel of this state gave up waiting for a peer workgroup (its outputs are then invalid);
- * synchronises the stream.  Never 1 unless the GPU was oversubscribed beyond the contract above. */
+/* 1 after a cooperative kernel of this state gave up waiting for a peer workgroup since the last call (the outputs of
+ * the steps in between are then invalid); READS AND CLEARS the word, synchronises the stream.  Never 1 unless the GPU was
+ * oversubscribed beyond the contract above. */
 int ptts_lm_state_error(ptts_lm_state *s, void *stream);
+/* Test hook: sets (value != 0) or clears the word ptts_lm_state_error reports. */
+int ptts_debug_set_error(ptts_lm_state *s, int32_t value, void *stream);
 /* A HIP stream restricted to CUs [cu_lo, cu_hi) of every XCD (hipExtStreamCreateWithCUMask; 32 CUs per XCD on
  * MI355X): work queued on it - eager launches and graph launches alike - leaves the other CUs to the other streams.
  * Destroy with ptts_stream_destroy after the work queued on it has finished. */

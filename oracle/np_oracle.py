@@ -95,8 +95,17 @@ def streaming_attention(x, state, wqkv, wo, num_heads, context, max_period):
     (reference `transformer.py:135-158`, cache `transformer.py:9-19,39-84`,
     mask `transformer.py:22-29`).  state = {"cache": [2,B,Tcap,H,D], "offset": int}."""
     B, T, C = x.shape
+    proj = linear(x, wqkv)
+    return linear(attention_core(proj, state, num_heads, context, max_period), wo)
+
+
+def attention_core(proj, state, num_heads, context, max_period):
+    """the part of `StreamingMultiheadAttention.forward` between the packed in_proj and out_proj
+    (reference `transformer.py:138-157`): proj [B, T, 3C] -> attention output [B, T, C]"""
+    B, T, C3 = proj.shape
+    C = C3 // 3
     D = C // num_heads
-    proj = linear(x, wqkv).reshape(B, T, 3, num_heads, D)
+    proj = proj.reshape(B, T, 3, num_heads, D)
     q, k, v = proj[:, :, 0], proj[:, :, 1], proj[:, :, 2]
     off = int(state["offset"])
     q, k = apply_rope(q, k, off, max_period)
@@ -121,8 +130,7 @@ def streaming_attention(x, state, wqkv, wo, num_heads, context, max_period):
     p = p / p.sum(axis=-1, keepdims=True, dtype=F32)
     # masked-out keys may hold NaN (cache is NaN-initialised, `transformer.py:52-57`)
     Vz = np.where(mask.any(axis=0)[None, None, :, None], V, F32(0.0))
-    o = (p @ Vz).astype(F32).transpose(0, 2, 1, 3).reshape(B, T, C)
-    return linear(o, wo)
+    return (p @ Vz).astype(F32).transpose(0, 2, 1, 3).reshape(B, T, C)
 
 
 def transformer_layer(x, state, W, p, num_heads, context, max_period, taps=None):
@@ -531,3 +539,89 @@ def quantized_weights(W, groups=("attention", "ffn")):
             if name.startswith("flow_lm.transformer.layers.") and name.endswith(QUANT_GROUP_SUFFIXES[g]):
                 out[name] = quantize_dequantize_int8(W[name])
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# bf16 codec (BASELINE config #5, second half): a ROUNDING MODEL of the build's reduced-precision Mimi decoder, so that
+# the HIP bf16 path is checked against the oracle and not only against the build's own fp32 path.
+# The reference has no bf16 / quantised Mimi at all (docs/quantization.md:67-76), so there is nothing to pin this to:
+# parity of the bf16 path with the REFERENCE stays "unpinned".  What this model states is WHERE the build rounds:
+#   * every GEMM / conv weight to bf16 once (a LayerNorm that precedes a Linear has its gain multiplied in first and
+#     the fold vector s[n] is summed from the ROUNDED matrix; the constant c[n] = W beta + bias comes from the fp32 one);
+#   * every activation buffer the codec writes to HBM to bf16 at the producer (after bias / activation / residual):
+#     upsample output, residual stream after out_proj and after linear2, GELU(linear1), attention output, every SEANet
+#     conv output (the ELU'd copy and the raw skip copy are rounded separately);
+#   * q, k, v, the KV ring, the softmax, all accumulation and all epilogue arithmetic stay fp32; the last conv
+#     (n_filters -> 1 sample) uses the fp32 checkpoint weights on the bf16 activation.
+# Same algorithm as MimiDecoder.decode otherwise (reference `tts_model.py:449-455`, `mimi.py:89-94`,
+# `mimi_transformer.py:39-54`, `seanet.py:141-180`, `conv.py:93-163`).
+def bf16_round(x):
+    """round-to-nearest-even to bfloat16, returned as float32 (v_cvt_pk_bf16_f32)"""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)) << np.uint32(16)
+    return r.view(np.float32)
+
+
+def elu_fast(x):
+    """the build's epilogue ELU: x > 0 ? x : exp(x) - 1 in fp32 (absolute error ~1e-7 near 0, see ptts_kernels.h)"""
+    return np.where(x > 0, x, np.exp(np.minimum(x, F32(0.0))) - F32(1.0)).astype(F32)
+
+
+def lnfold_linear_bf16(x, w, g, beta, bias, eps):
+    """LayerNorm folded into the following Linear, bf16 weights (ptts_bf16.h PRE_LNFOLD): x holds bf16 values"""
+    wr = bf16_round(w * g[None, :])
+    s = wr.sum(axis=1, dtype=F32)
+    c = (w @ beta + (bias if bias is not None else F32(0))).astype(F32)
+    K = x.shape[-1]
+    mu = x.sum(axis=-1, dtype=F32) / F32(K)
+    var = np.maximum((x * x).sum(axis=-1, dtype=F32) / F32(K) - mu * mu, F32(0))
+    rs = F32(1.0) / np.sqrt(var + F32(eps))
+    return (((x @ wr.T) - mu[..., None] * s) * rs[..., None] + c).astype(F32)
+
+
+class MimiDecoderBF16(MimiDecoder):
+    def decode(self, st, latent, taps=None):
+        W = self.W
+        x = (latent * W["flow_lm.emb_std"] + W["flow_lm.emb_mean"]).astype(F32)
+        x = linear(x, W["mimi.quantizer.output_proj.weight"][:, :, 0])[:, :, None]   # fp32 (kept per frame in fp32)
+        wu = W["mimi.upsample.convtr.convtr.weight"][:, 0, :]
+        y = (x * wu[None]).astype(F32)
+        s = self.stride
+        y[..., :s] += st["upsample"]["partial"]
+        st["upsample"]["partial"] = y[..., s:].copy()
+        h = bf16_round(y[..., :s]).transpose(0, 2, 1)                                # [B, T, C], bf16 values
+        tr = self.tr
+        for i in range(tr.num_layers):
+            p = f"mimi.decoder_transformer.transformer.layers.{i}"
+            proj = lnfold_linear_bf16(h, W[p + ".self_attn.in_proj.weight"], W[p + ".norm1.weight"], W[p + ".norm1.bias"], None, 1e-5)
+            ao = bf16_round(attention_core(proj, st["attn"][i], tr.num_heads, tr.context, float(tr.max_period)))
+            a = linear(ao, bf16_round(W[p + ".self_attn.out_proj.weight"]))
+            h = bf16_round(h + W[p + ".layer_scale_1.scale"] * a)
+            f = lnfold_linear_bf16(h, W[p + ".linear1.weight"], W[p + ".norm2.weight"], W[p + ".norm2.bias"], None, 1e-5)
+            f = linear(bf16_round(gelu(f)), bf16_round(W[p + ".linear2.weight"]))
+            h = bf16_round(h + W[p + ".layer_scale_2.scale"] * f)
+        for a_ in st["attn"]:
+            a_["offset"] += s
+        x = h.transpose(0, 2, 1).astype(F32)
+        # SEANet: `x` is always the bf16 buffer the next conv reads (ELU already applied by its producer), `raw` the
+        # bf16 copy of the un-activated value a residual block adds back
+        raw = None
+        last = len(self.layers) - 1
+        for n, (idx, kind, cin, cout, k, stride) in enumerate(self.layers):
+            p = f"mimi.decoder.model.{idx}"
+            if kind == "conv" and n == last:
+                w = W[p + ".conv.weight"]                                         # fp32 weights on the bf16 activation
+                x = streaming_conv1d(x, w, W[p + ".conv.bias"], st[idx])
+            elif kind == "conv":
+                v = streaming_conv1d(x, bf16_round(W[p + ".conv.weight"]), W[p + ".conv.bias"], st[idx])
+                x = bf16_round(elu_fast(v))
+            elif kind == "convtr":
+                v = streaming_conv_transpose1d(x, bf16_round(W[p + ".convtr.weight"]), W[p + ".convtr.bias"], stride, st[idx])
+                raw, x = bf16_round(v), bf16_round(elu_fast(v))
+            else:
+                v = streaming_conv1d(x, bf16_round(W[p + ".block.1.conv.weight"]), W[p + ".block.1.conv.bias"], st[idx])
+                v = conv1d(bf16_round(elu_fast(v)), bf16_round(W[p + ".block.3.conv.weight"]), W[p + ".block.3.conv.bias"])
+                x = bf16_round(elu_fast(raw + v))
+            if taps is not None:
+                taps[f"seanet{idx}"] = x.copy()
+        return x[:, 0, :]

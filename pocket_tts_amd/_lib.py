@@ -54,6 +54,7 @@ PROTOTYPES = {
     "ptts_lm_state_export": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P]),
     "ptts_lm_state_copy": (C.c_int, [_P, _P, _P]),
     "ptts_lm_state_copy_row": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "ptts_lm_state_copy_row_from": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P]),
     "ptts_lm_state_offsets": (C.c_int, [_P, C.POINTER(C.c_int32), _P]),
     "ptts_lm_prefill": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
     "ptts_lm_decode_step": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_float, _P, _P, _P, _P]),
@@ -85,6 +86,7 @@ PROTOTYPES = {
     "ptts_tune_version": (C.c_int, []),
     "ptts_set_option": (C.c_int, [_P, C.c_char_p, C.c_int32]),
     "ptts_lm_state_error": (C.c_int, [_P, _P]),
+    "ptts_debug_set_error": (C.c_int, [_P, C.c_int32, _P]),
     "ptts_stream_create_masked": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(_P)]),
     "ptts_stream_destroy": (C.c_int, [_P]),
     "ptts_sync": (C.c_int, [_P, _P]),
@@ -100,17 +102,45 @@ PROTOTYPES = {
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile csrc/ptts.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    deps = [SRC, *sorted(SRC.parent.glob("*.h")), HEADER]
-    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
-        return LIB_PATH
+    """Compile csrc/*.hip for gfx950 in-tree (hipcc cross-compiles without a GPU).  Every .hip file is one translation
+    unit (ptts.hip = host side + the round-1/2 kernels; newer kernel families live in their own files behind plain C++
+    launcher functions declared in ptts_ext.h), compiled in parallel to csrc/.obj/*.o and linked into libptts.so; a
+    unit is recompiled when it or any header is newer than its object."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    srcs = sorted(SRC.parent.glob("*.hip"))
+    hdrs = [*sorted(SRC.parent.glob("*.h")), HEADER]
+    obj_dir = SRC.parent / ".obj"
+    obj_dir.mkdir(exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *HIPCC_FLAGS, "-o", str(LIB_PATH), str(SRC)]
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    newest_hdr = max(h.stat().st_mtime for h in hdrs)
+
+    def stale(src):
+        o = obj_dir / (src.stem + ".o")
+        return force or not o.exists() or o.stat().st_mtime < max(src.stat().st_mtime, newest_hdr)
+
+    todo = [s for s in srcs if stale(s)]
+    objs = [obj_dir / (s.stem + ".o") for s in srcs]
+    if not todo and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= o.stat().st_mtime for o in objs):
+        return LIB_PATH
+
+    def compile_one(src):
+        cmd = [hipcc, *cflags, "-c", "-o", str(obj_dir / (src.stem + ".o")), str(src)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        return src, subprocess.run(cmd, capture_output=True, text=True)
+
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(todo)))) as ex:
+        for src, r in ex.map(compile_one, todo):
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src.name}:\n{r.stdout}\n{r.stderr}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH), *map(str, objs)]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
+        raise RuntimeError(f"hipcc link failed:\n{r.stdout}\n{r.stderr}")
     return LIB_PATH
 
 

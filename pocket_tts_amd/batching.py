@@ -42,6 +42,25 @@ def eos_bookkeeping(local_step: int, max_gen_len: int, frames_after_eos: int, eo
     return eos_step, None
 
 
+def eos_bookkeeping_rows(local_step, max_gen_len, frames_after_eos, eos_step, n_emit, flags, rows=None):
+    """`eos_bookkeeping` for many rows at once, in place on the int arrays `eos_step` / `n_emit` (-1 = None).
+    `local_step`: scalar or array (rows of a continuous batch are at different steps of their utterances); rows whose
+    `n_emit` is already decided, or that `rows` (bool mask) excludes, are left alone."""
+    import numpy as np
+
+    run = n_emit < 0
+    if rows is not None:
+        run = run & rows
+    ls = np.broadcast_to(np.asarray(local_step), n_emit.shape)
+    maxed = run & (ls >= max_gen_len)
+    n_emit[maxed] = np.broadcast_to(max_gen_len, n_emit.shape)[maxed]
+    run = run & ~maxed
+    first = run & flags & (eos_step < 0)
+    eos_step[first] = ls[first]
+    done = run & (eos_step >= 0) & (ls >= eos_step + frames_after_eos)
+    n_emit[done] = ls[done]
+
+
 class Request:
     """One submitted text.  Iterate to receive chunks; `result()` waits for the whole waveform."""
 
@@ -71,19 +90,24 @@ class Request:
 class _Job:
     """one text chunk of a request while it owns a slot"""
 
-    __slots__ = ("req", "tokens", "voice", "gen", "fae", "start", "eos_step", "n_emit", "routed", "last")
+    __slots__ = ("req", "tokens", "voice", "gen", "fae", "start", "last")
 
     def __init__(self, req, tokens, voice, gen, fae, last):
         self.req, self.tokens, self.voice, self.gen, self.fae, self.last = req, tokens, voice, gen, fae, last
         self.start = None      # global step of its first FlowLM step
-        self.eos_step = None   # local step of the first EOS flag
-        self.n_emit = None     # frames to keep, known when the row leaves
-        self.routed = 0        # frames handed to the request so far
 
 
 class ContinuousBatcher:
     def __init__(self, model, slots: int = 16, capacity: int = 1024, pcm_format: str = "f32", noise_seed: int = 0):
-        """`capacity`: KV positions per slot (voice + text + generated frames of one chunk must fit)."""
+        """`capacity`: KV positions per slot (voice + text + generated frames of one chunk must fit).
+
+        The scheduler never waits for the GPU on the step path: FlowLM step g and codec frame g are queued on the two
+        streams of the "events" pipeline, and the EOS flags / PCM of a step are read from pinned memory `lag` <= nb steps
+        later (as soon as the frame's event has fired).  A row therefore runs up to nb steps past the end of its
+        utterance before its slot is parked (those frames are dropped); frame counts and waveforms are exactly those of
+        the reference's loop (tts_model.py:756-768 per row)."""
+        import numpy as np
+
         from .engine import StepPipeline
 
         if pcm_format not in ("f32", "i16"):
@@ -98,13 +122,18 @@ class ContinuousBatcher:
         for b in range(slots):
             self.st.set_row_active(b, False)
         self.pipe = StepPipeline(eng, self.st, self.ms, None, model.lsd_decode_steps, float(model.eos_threshold),
-                                 mode="hostsync", pcm_i16=(pcm_format == "i16"))
+                                 mode="events", pcm_i16=(pcm_format == "i16"))
         self.pipe.restart()
         self.slot: list = [None] * slots                 # running _Job per slot
-        self.history = [collections.deque(maxlen=4) for _ in range(slots)]  # jobs whose frames may still be in flight
+        # per-slot bookkeeping of the job that owns the slot (arrays: one numpy pass per step instead of a Python loop)
+        self.a_start = np.zeros(slots, np.int64)
+        self.a_gen = np.zeros(slots, np.int64)
+        self.a_fae = np.zeros(slots, np.int64)
+        self.a_eos = np.full(slots, -1, np.int64)
+        self.a_emit = np.full(slots, 0, np.int64)         # >= 0: no running job in the slot
         self.waiting: collections.deque = collections.deque()
         self.g = 0            # global step counter == pipe.t
-        self.collected = 0    # frames [0, collected) have been routed
+        self.collected = 0    # frames [0, collected) have been read (EOS flags) and routed (PCM)
         self._next_id = 0
         self._lock = threading.Lock()
         self._wake = threading.Condition(self._lock)
@@ -139,8 +168,9 @@ class ContinuousBatcher:
                 m.model_recommended_frames_after_eos if m.model_recommended_frames_after_eos is not None else guess + 2)
             ids = m.tokenizer.encode(chunk)
             gen = estimate_max_gen_len(len(ids), m.config.mimi.frame_rate)
-            if t_voice + len(ids) + gen + 1 > self.capacity:
-                raise ValueError(f"request needs {t_voice + len(ids) + gen + 1} KV positions; slot capacity is {self.capacity}")
+            need = t_voice + len(ids) + gen + self.pipe.nb + 2  # a row runs up to nb steps past its end before it is parked
+            if need > self.capacity:
+                raise ValueError(f"request needs {need} KV positions; slot capacity is {self.capacity}")
             jobs.append(_Job(req, torch.tensor(ids, dtype=torch.long)[None, :], model_state, gen, fae, i == len(chunks) - 1))
         req._pending_chunks = len(jobs)
         with self._wake:
@@ -156,38 +186,61 @@ class ContinuousBatcher:
 
     # ---- scheduler (one thread) ----------------------------------------------------------------
     def _admit(self):
-        from .tts_model import _state_current_end
-
+        """Waiting jobs join the free slots.  Jobs with the same voice state and token count are prefilled as ONE batch
+        (voice KV cloned from its device-resident copy, one GEMM pass for the group) and dealt to their slots; nothing
+        synchronises with the host."""
         eng = self.eng
-        while True:
-            with self._lock:
-                free = [b for b in range(self.B) if self.slot[b] is None]
-                if not free or not self.waiting:
-                    return
-                job = self.waiting.popleft()
-            b = free[0]
-            one = None
+        with self._lock:
+            free = [b for b in range(self.B) if self.slot[b] is None and self.a_emit[b] >= 0]
+            take = []
+            while self.waiting and len(take) < len(free):
+                take.append(self.waiting.popleft())
+        if not take:
+            return
+        groups: dict = {}
+        for job in take:
+            groups.setdefault((id(job.voice), job.tokens.shape[1]), []).append(job)
+        for jobs in groups.values():
             try:
-                voice_st, t_voice = self.model._voice_lm_state(job.voice)  # device-resident voice, no host sync
-                Tt = job.tokens.shape[1]
-                one = eng.new_lm_state(1, t_voice + Tt)
-                one.copy_from(voice_st)
-                eng.lm_prefill(one, eng.embed_text(job.tokens))
-                self.st.copy_row_from(b, one)       # KV rows, position, BOS as the pending input, row active
-                eng.sync()
+                self._admit_group(jobs, [free.pop(0) for _ in jobs])
             except (ValueError, KeyError, IndexError, TypeError) as e:
-                # a bad request (malformed voice state, capacity): fail THIS request, keep serving the others.  The job
-                # is in no list any more, so it is notified here (its consumer used to block forever).
-                self._end_request(job.req, e)
-                continue
-            finally:
-                if one is not None:
-                    one.close()
+                if len(jobs) == 1:
+                    # a bad request (malformed voice state, capacity): fail THIS request, keep serving the others.  The
+                    # job is in no list any more, so it is notified here (its consumer would block forever).
+                    self._end_request(jobs[0].req, e)
+                    continue
+                for job in jobs:  # find the bad one(s): admit the group's members one by one
+                    with self._lock:
+                        b = next(b for b in range(self.B) if self.slot[b] is None and self.a_emit[b] >= 0)
+                    try:
+                        self._admit_group([job], [b])
+                    except (ValueError, KeyError, IndexError, TypeError) as e1:
+                        self._end_request(job.req, e1)
+
+    def _admit_group(self, jobs, rows):
+        eng, model = self.eng, self.model
+        voice = model._voice_acquire(jobs[0].voice)  # device-resident voice, no host sync on a hit
+        grp = None
+        try:
+            voice_st, t_voice = voice
+            Tt = jobs[0].tokens.shape[1]
+            grp = eng.new_lm_state(len(jobs), t_voice + Tt)
+            grp.copy_from(voice_st)
+            eng.lm_prefill(grp, eng.embed_text(torch.cat([j.tokens for j in jobs], dim=0)))
+            for i, b in enumerate(rows):
+                self.st.copy_row_from(b, grp, i)   # KV rows, position, BOS as the pending input, row active
+            eng.sync()  # the group state is freed below; its clone kernels must have run
+        finally:
+            if grp is not None:
+                grp.close()
+            model._voice_release(voice)
+        for job, b in zip(jobs, rows):
             # the slot's codec carries: zero on the codec stream, behind the frames already queued there
             self.ms.reset_row(b, self.pipe.s2)
             job.start = self.g
             self.slot[b] = job
-            self.history[b].append(job)
+            self.a_start[b], self.a_gen[b], self.a_fae[b] = self.g, job.gen, job.fae
+            self.a_eos[b], self.a_emit[b] = -1, -1
 
     def _end_request(self, req, error: Exception | None = None):
         """final sentinel of a request (with `error`: the consumer's iteration raises it); drops its follow-up chunks"""
@@ -199,80 +252,79 @@ class ContinuousBatcher:
             req.error = error
         req._q.put(None)
 
-    def _route(self, frame: int):
-        """hand the rows of decoded `frame` to their requests"""
-        pipe = self.pipe
-        pipe.done_event(frame).synchronize()
-        pcm = pipe.pcm16_of(frame) if self.pcm_format == "i16" else pipe.pcm_of(frame)
-        for b in range(self.B):
-            for job in self.history[b]:
-                if job.start is None or frame < job.start:
-                    continue
-                local = frame - job.start
-                if job.n_emit is not None and local >= job.n_emit:
-                    continue
-                if local != job.routed:
-                    continue  # belongs to another job of this slot
-                job.req._q.put(pcm[b].clone())
-                job.req.frames += 1
-                job.routed += 1
-        self._finish_done()
+    def _process(self, frame: int):
+        """EOS decisions of FlowLM step `frame` and the PCM of codec frame `frame`, for every slot whose job had started
+        by then; rows whose loop breaks at this step leave their slot (the break-step frame is not emitted)."""
+        import numpy as np
 
-    def _finish_done(self):
-        for b in range(self.B):
-            for job in list(self.history[b]):
-                if job.n_emit is not None and job.routed >= job.n_emit and job.req is not None:
-                    req = job.req
-                    job.req = None
-                    self.history[b].remove(job)
-                    with self._wake:
-                        req._pending_chunks -= 1
-                        nxt = self._chain.get(req.id)
-                        if nxt:
-                            self.waiting.appendleft(nxt.popleft())
-                            if not nxt:
-                                del self._chain[req.id]
-                        elif req._pending_chunks == 0:
-                            self._outstanding.pop(req.id, None)
-                            req._q.put(None)
+        pipe = self.pipe
+        pipe.done_event(frame).synchronize()  # codec frame done => the FlowLM step's flags are on the host too
+        q = frame % pipe.nb
+        rows = (self.a_emit < 0) & (self.a_start <= frame)
+        if not rows.any():
+            return
+        eos_bookkeeping_rows(frame - self.a_start, self.a_gen, self.a_fae, self.a_eos, self.a_emit,
+                             pipe.flag[q].numpy() != 0, rows)
+        # one copy of the frame out of the pinned ring (numpy memcpy: no intra-op thread team), rows are views of it
+        pcm = torch.from_numpy((pipe.pcm16_of(frame) if self.pcm_format == "i16" else pipe.pcm_of(frame)).numpy().copy())
+        for b in np.nonzero(rows)[0]:
+            job = self.slot[b]
+            if self.a_emit[b] < 0:
+                job.req._q.put(pcm[b])
+                job.req.frames += 1
+                continue
+            if self.a_eos[b] < 0:
+                logger.warning("Maximum generation length reached without EOS, this very often indicates an error.")
+            self.st.set_row_active(int(b), False)
+            self.slot[b] = None
+            self._finish(job)
+
+    def _finish(self, job):
+        req = job.req
+        with self._wake:
+            req._pending_chunks -= 1
+            nxt = self._chain.get(req.id)
+            if nxt:
+                self.waiting.appendleft(nxt.popleft())
+                if not nxt:
+                    del self._chain[req.id]
+            elif req._pending_chunks == 0:
+                self._outstanding.pop(req.id, None)
+                req._q.put(None)
+
+    def _check_gpu_error(self):
+        if self.st.error():  # synchronises the FlowLM stream: only called when idle / every 512 steps
+            raise RuntimeError("libptts: a cooperative FlowLM kernel timed out; audio generated since the last check is invalid")
 
     def step(self) -> bool:
-        """One scheduler iteration: admit, FlowLM step g, route frame g-2, EOS decisions of step g, codec frame g.
+        """One scheduler iteration: admit, read the steps whose frames are complete, queue FlowLM step g + codec frame g.
         Returns False when there is nothing to run."""
         self._admit()
+        pipe, nb = self.pipe, self.pipe.nb
+        # mandatory for frame g - nb (its pinned buffers are about to be reused), opportunistic for the later ones
+        while self.collected < self.g and (self.g - self.collected >= nb or pipe.done_event(self.collected).query()):
+            self._process(self.collected)
+            self.collected += 1
         if all(j is None for j in self.slot):
             self._drain()
             return bool(self.waiting)
-        pipe, g = self.pipe, self.g
-        pipe.lm_step_async()
-        if g - 2 >= self.collected:  # before its pinned buffer is reused by frame g
-            self._route(g - 2)
-            self.collected = g - 1
-        flags = pipe.wait_flags(g)
-        for b, job in enumerate(self.slot):
-            if job is None:
-                continue
-            job.eos_step, job.n_emit = eos_bookkeeping(g - job.start, job.gen, job.fae, job.eos_step, bool(flags[b].item()))
-            if job.n_emit is not None:
-                if job.eos_step is None:
-                    logger.warning("Maximum generation length reached without EOS, this very often indicates an error.")
-                self.st.set_row_active(b, False)
-                self.slot[b] = None
-        pipe.decode_async(g)
+        pipe.step()
         self.g += 1
-        self._finish_done()
+        if self.g % 512 == 0:
+            self._check_gpu_error()
         return True
 
     def _drain(self):
-        """route the frames still in flight (nothing is running)"""
+        """read the frames still in flight (nothing is queued behind them)"""
         while self.collected < self.g:
-            self._route(self.collected)
+            self._process(self.collected)
             self.collected += 1
 
     def run_until_idle(self):
         while self.step():
             pass
         self._drain()
+        self._check_gpu_error()
 
     # ---- background operation ------------------------------------------------------------------
     def start(self):
@@ -285,7 +337,9 @@ class ContinuousBatcher:
                     idle = not self.waiting and all(j is None for j in self.slot)
                 try:
                     if idle:
-                        self._drain()  # the last frames of the rows that just left; may queue a follow-up chunk
+                        if self.collected < self.g:
+                            self._drain()  # the last frames of the rows that just left; may queue a follow-up chunk
+                            self._check_gpu_error()
                         with self._wake:
                             if not self._stop and not self.waiting:
                                 self._wake.wait(timeout=0.05)

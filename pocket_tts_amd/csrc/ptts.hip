@@ -129,6 +129,7 @@ struct ptts_engine {
   int opt_codec_lds_target = 56 * 1024;  // see lds_pad()
   int opt_fuse_res = 1;  // SEANet residual blocks of stages 2 and 3 as one launch each (gemm_lds_kernel<.., NT2>)
   int opt_flow_max_cus = 128;  // resident workgroups of the single-launch flow MLP (<= the CUs its stream may use)
+  int n_cus = 256;             // hipDeviceProp_t::multiProcessorCount of `device` (cooperative grids never exceed it)
   std::recursive_mutex mu;  // entry points that enqueue work or touch tuner / profiler / LSD tables hold it
   int quant_flags = 0;
 };
@@ -154,6 +155,8 @@ struct ptts_lm_state {
   unsigned long long *fflags = nullptr;
   int *ferr = nullptr;
   int flow_steps = 0, flow_rt = 1, flow_ng = 1;
+  int n_graphs = 0;   // captured graphs that hold this state's buffer pointers (ensure_flow must not re-allocate under them)
+  int coop_wgs = 0;   // workgroups of the cooperative launch of the last enqueued step (0: per-layer launches)
   // single-launch transformer stack (lm_cluster_kernel): exchange slots + flags, allocated on first use
   float *lexch = nullptr;
   unsigned long long *lflags = nullptr;
@@ -199,6 +202,8 @@ struct ptts_graph {
   ptts_lm_state *lm = nullptr;
   ptts_mimi_state *mimi = nullptr;
   hipStream_t cap_stream = nullptr;
+  int coop_wgs = 0;  // workgroups of the largest cooperative launch inside (0: none): the launch stream needs that many CUs
+  hipStream_t cu_checked = nullptr;  // the last launch stream whose CU mask was found large enough (checked once per stream)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -417,7 +422,7 @@ static void launch_cfg_q8(hipStream_t st, const GemmArgs &a, int pre) {
 // Occupancy cap of the codec's GEMM launches (engine option "codec_lds_target", bytes <= 64 KB; 0 = off): they request
 // dynamic LDS up to this total per workgroup, which limits their workgroups per CU to 160 KB / target and leaves wave slots
 // and registers for the FlowLM stream's kernels, whose dependent chain is what the pipelined step waits for.  Measured at
-// batch 64 (tools/ab_env.sh PTTS_CODEC_LDS_TARGET, final kernels): 0 -> 0.893 ms per step, 36 KB (4 per CU) -> 0.882,
+// batch 64 (tools/ab.sh env PTTS_CODEC_LDS_TARGET, final kernels): 0 -> 0.893 ms per step, 36 KB (4 per CU) -> 0.882,
 // 44 KB (3) -> 0.864, 56 KB (2) -> 0.851; the codec graph alone 0.548 -> 0.554 (44 KB) -> 0.589 ms (56 KB).
 static thread_local int g_lds_target = 0;
 static unsigned lds_pad(int static_bytes) { return g_lds_target > static_bytes ? (unsigned)(g_lds_target - static_bytes) : 0u; }
@@ -441,7 +446,7 @@ static void launch_lds(hipStream_t st, const GemmArgs &a, int pre) {
   dim3 grid(cdiv(a.NT, BNT), cdiv(a.MT, BMT));
   // Under the occupancy cap the padded LDS is free, so the capped launches run a THREE-stage ring (two stages in flight
   // with two workgroups per CU): 0.862 -> 0.857 ms per pipelined step; four k-fragments per stage instead: 0.909
-  // (tools/ab_env.sh PTTS_LDS_VARIANT 0 / 1 / 2).  Uncapped launches keep two stages (never slower, round 1).
+  // (tools/ab.sh env PTTS_LDS_VARIANT 0 / 1 / 2).  Uncapped launches keep two stages (never slower, round 1).
   static const int variant = [] { const char *v = getenv("PTTS_LDS_VARIANT"); return v ? atoi(v) : 1; }();
   if constexpr (BMT == 4 && BNT <= 4) {
     if (variant == 1 && g_lds_target) {
@@ -594,7 +599,7 @@ __global__ void flush_read_kernel(const f32x4 *p, size_t n, float *sink) {
 
 static int tune_one(hipStream_t st, const GemmArgs &a, int pre, Tuner &t) {
   // tiles are timed WITHOUT the codec's occupancy cap: under it the LDS-staged tiles look slower alone and the search drifts
-  // to the register-heavy K-split tiles, which cost the pipelined step 6 % (tools/ab_retune.sh)
+  // to the register-heavy K-split tiles, which cost the pipelined step 6 % (tools/ab.sh cache)
   struct NoCap { int keep; NoCap() : keep(g_lds_target) { g_lds_target = 0; } ~NoCap() { g_lds_target = keep; } } nocap;
   int best = pick_cfg(a);
   float best_ms = 1e30f, heur_ms = 0.f;
@@ -754,7 +759,7 @@ static int attn_wave_target() {
 // waves per workgroup of attn_kernel (they split the workgroup's key tiles and merge in LDS, no combine launch).
 // Only for small launches: on the codec frame at batch 64 (512 (sequence, head) pairs, 17 key tiles) 4 waves x 1 split
 // is faster alone (18.2 us against 19.8 us + the combine launch, tests/hip/sweep_attn.hip) but SLOWER in the two-stream
-// pipeline (0.958 vs 0.947 ms per step, 2 waves 0.963 vs 0.955; tools/ab_attn_nw.sh): the extra resident waves delay
+// pipeline (0.958 vs 0.947 ms per step, 2 waves 0.963 vs 0.955; tools/ab.sh env PTTS_ATTN_KERNEL_NW): the extra resident waves delay
 // the FlowLM stream's kernels.  At batch 8 / 1 it saves 1.5 / 1.1 us per layer.
 static int attn_nw(int base) {
   static const int forced = [] { const char *v = getenv("PTTS_ATTN_KERNEL_NW"); return v ? atoi(v) : 0; }();  // A/B knob
@@ -774,7 +779,7 @@ static void launch_attn(hipStream_t st, const AttnArgs &at, int BH) {
   const dim3 grid(BH, at.QB, at.splits);
   const int nw = attn_nw(BH * at.QB);
   // large launches (one wave per workgroup) keep two register tiles instead of three: 32 registers less per wave, 0.854 ->
-  // 0.850 ms per pipelined step at batch 64 (tools/ab_env.sh PTTS_ATTN_DEPTH)
+  // 0.850 ms per pipelined step at batch 64 (tools/ab.sh env PTTS_ATTN_DEPTH)
   static const int depth = [] { const char *v = getenv("PTTS_ATTN_DEPTH"); return v ? atoi(v) : 2; }();  // A/B knob
   if (nw == 4) attn_kernel<4><<<grid, 256, 0, st>>>(at);
   else if (nw == 2) attn_kernel<2><<<grid, 128, 0, st>>>(at);
@@ -824,7 +829,7 @@ static void run_tr_layer(hipStream_t st, const TrLayer &T, const TrCtx &c) {
       // the row-state kernel (no cross-row traffic in its loop).  Small batches: three register tiles (6.0 vs 7.2 us per
       // layer at batch 1, 221 keys).  >= 1024 (sequence, head) pairs: TWO register tiles - alone it streams at the rate of
       // the first kernel (attn_decode_kernel, 188 VGPRs, still selectable with PTTS_ATTN_V=1), but at ~110 registers per wave
-      // it leaves the codec stream its occupancy: 0.904 -> 0.877 ms per pipelined step at batch 64 (tools/ab_env.sh
+      // it leaves the codec stream its occupancy: 0.904 -> 0.877 ms per pipelined step at batch 64 (tools/ab.sh env
       // PTTS_ATTN_V; three tiles: 0.881)
       if (nw >= 8) attn_decode2_kernel<8, 3><<<dim3(BH, 1, c.splits), 512, 0, st>>>(at);
       else if (nw == 4) attn_decode2_kernel<4, 3><<<dim3(BH, 1, c.splits), 256, 0, st>>>(at);
@@ -862,8 +867,13 @@ extern "C" int ptts_abi_version(void) { return PTTS_ABI_VERSION; }
 extern "C" const char *ptts_last_error(void) { return g_err.c_str(); }
 
 static int seanet_check(const ptts_config &c) {
-  if (c.d_model % 64 || c.d_model / c.num_heads != 64) return fail(-4, "FlowLM head dim must be 64");
-  if (c.m_dim / c.m_heads != 64) return fail(-4, "Mimi head dim must be 64");
+  // an untrusted config (a packed-engine file) reaches this function: no division before the divisors are checked
+  if (c.d_model < 64 || c.num_heads < 1 || c.num_layers < 1 || c.m_dim < 64 || c.m_heads < 1 || c.m_layers < 1 || c.ldim < 16 ||
+      c.flow_dim < 16 || c.flow_depth < 1 || c.ff_dim < 16 || c.m_ff < 16 || c.n_filters < 1 || c.compress < 1 ||
+      c.kernel_size < 1 || c.res_kernel_size < 1 || c.last_kernel_size < 1 || c.ratios[0] < 1 || c.ratios[1] < 1 || c.ratios[2] < 1)
+    return fail(-4, "model dimensions must be positive");
+  if (c.d_model % 64 || c.d_model / c.num_heads != 64 || c.d_model % c.num_heads) return fail(-4, "FlowLM head dim must be 64");
+  if (c.m_dim % c.m_heads || c.m_dim / c.m_heads != 64) return fail(-4, "Mimi head dim must be 64");
   if (c.d_model > 1024 || c.m_dim > 1024 || c.flow_dim > 1024) return fail(-4, "LayerNorm width > 1024 unsupported");
   if (c.ldim % 16 || c.flow_dim % 16 || c.ff_dim % 16 || c.m_ff % 16) return fail(-4, "dims must be multiples of 16");
   if (c.upsample_stride != 16) return fail(-4, "upsample stride must be 16 (one row tile per frame)");
@@ -873,6 +883,23 @@ static int seanet_check(const ptts_config &c) {
 
 static int build_engine(ptts_engine *e, const ptts_tensor *tensors, int32_t n);
 
+// device properties + the option defaults from the environment: shared by ptts_create_ex and ptts_create_from_file
+static int init_engine_options(ptts_engine *e, int device) {
+  e->device = device;
+  e->tuner = new Tuner();
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  e->n_cus = std::max(1, prop.multiProcessorCount);
+  if (const char *v = getenv("PTTS_FLOW_CLUSTER")) e->opt_flow_cluster = atoi(v) != 0;
+  if (const char *v = getenv("PTTS_LM_CLUSTER")) e->opt_lm_cluster = atoi(v) != 0;
+  if (const char *v = getenv("PTTS_K_ROTATE")) e->opt_k_rotate = atoi(v) != 0;
+  if (const char *v = getenv("PTTS_FUSE_RES")) e->opt_fuse_res = atoi(v) != 0;
+  if (const char *v = getenv("PTTS_FLOW_MAX_CUS")) e->opt_flow_max_cus = std::max(8, atoi(v));
+  e->opt_flow_max_cus = std::min(e->opt_flow_max_cus, e->n_cus);  // a cooperative grid never exceeds the device
+  if (const char *v = getenv("PTTS_CODEC_LDS_TARGET")) e->opt_codec_lds_target = std::max(0, std::min(atoi(v), 64 * 1024));
+  return 0;
+}
+
 extern "C" int ptts_create(const ptts_config *cfg, const ptts_tensor *tensors, int32_t n, int32_t device,
                            ptts_engine **out) {
   return ptts_create_ex(cfg, tensors, n, device, 0, out);
@@ -881,21 +908,16 @@ extern "C" int ptts_create(const ptts_config *cfg, const ptts_tensor *tensors, i
 extern "C" int ptts_create_ex(const ptts_config *cfg, const ptts_tensor *tensors, int32_t n, int32_t device,
                               int32_t quant_flags, ptts_engine **out) {
   if (!cfg || !tensors || !out) return fail(-1, "null argument");
-  if (quant_flags & ~(PTTS_QUANT_ATTENTION | PTTS_QUANT_FFN | PTTS_CODEC_BF16)) return fail(-1, "unknown quantisation group");
+  if (quant_flags & ~(PTTS_QUANT_ATTENTION | PTTS_QUANT_FFN | PTTS_CODEC_BF16 | PTTS_CODEC_FP8 | PTTS_LM_BF16)) return fail(-1, "unknown quantisation group");
+  if ((quant_flags & PTTS_CODEC_BF16) && (quant_flags & PTTS_CODEC_FP8)) return fail(-1, "PTTS_CODEC_BF16 and PTTS_CODEC_FP8 are exclusive");
+  if ((quant_flags & PTTS_LM_BF16) && (quant_flags & (PTTS_QUANT_ATTENTION | PTTS_QUANT_FFN))) return fail(-1, "PTTS_LM_BF16 and the int8 groups are exclusive");
   CHK(seanet_check(*cfg));
   HIPCHK(hipSetDevice(device));
   ptts_engine *e = new ptts_engine();
   e->cfg = *cfg;
-  e->device = device;
-  e->tuner = new Tuner();
   e->quant_flags = quant_flags;
-  if (const char *v = getenv("PTTS_FLOW_CLUSTER")) e->opt_flow_cluster = atoi(v) != 0;
-  if (const char *v = getenv("PTTS_LM_CLUSTER")) e->opt_lm_cluster = atoi(v) != 0;
-  if (const char *v = getenv("PTTS_K_ROTATE")) e->opt_k_rotate = atoi(v) != 0;
-  if (const char *v = getenv("PTTS_FUSE_RES")) e->opt_fuse_res = atoi(v) != 0;
-  if (const char *v = getenv("PTTS_FLOW_MAX_CUS")) e->opt_flow_max_cus = std::max(8, std::min(atoi(v), 256));
-  if (const char *v = getenv("PTTS_CODEC_LDS_TARGET")) e->opt_codec_lds_target = std::max(0, std::min(atoi(v), 64 * 1024));
-  const int rc = build_engine(e, tensors, n);
+  int rc = init_engine_options(e, device);
+  if (rc == 0) rc = build_engine(e, tensors, n);
   if (rc < 0) {  // missing / ill-shaped tensor, HIP error: release what was built so far
     const std::string msg = g_err;
     ptts_destroy(e);
@@ -1121,6 +1143,10 @@ extern "C" int ptts_create_from_file(const char *path, int32_t device, ptts_engi
   }
   std::vector<int64_t> sizes((size_t)h.n_allocs);
   if (fread(sizes.data(), 8, sizes.size(), f) != sizes.size()) { fclose(f); return fail(-3, "truncated packed engine (sizes)"); }
+  if (h.quant_flags & ~(PTTS_QUANT_ATTENTION | PTTS_QUANT_FFN | PTTS_CODEC_BF16 | PTTS_CODEC_FP8 | PTTS_LM_BF16)) {
+    fclose(f);
+    return fail(-3, "packed engine carries unknown weight-format flags");
+  }
   if (seanet_check(h.cfg) < 0) { fclose(f); return -4; }
   if (hipSetDevice(device) != hipSuccess) { fclose(f); return fail(-2, "hipSetDevice"); }
   // the largest checkpoint tensor any packing kernel reads (a zero stand-in: the images it produces are overwritten)
@@ -1137,13 +1163,11 @@ extern "C" int ptts_create_from_file(const char *path, int32_t device, ptts_engi
   ptts_tensor dummy{"<packed>", zeros, -1};
   ptts_engine *e = new ptts_engine();
   e->cfg = h.cfg;
-  e->device = device;
-  e->tuner = new Tuner();
   e->quant_flags = h.quant_flags;
-  if (const char *v = getenv("PTTS_FLOW_CLUSTER")) e->opt_flow_cluster = atoi(v) != 0;
   e->blob_dummy = &dummy;
   e->blob_has_encoder = h.has_encoder;
-  int rc = build_engine(e, nullptr, 0);
+  int rc = init_engine_options(e, device);
+  if (rc == 0) rc = build_engine(e, nullptr, 0);
   e->blob_dummy = nullptr;
   std::string msg = g_err;
   if (rc == 0 && (int64_t)e->n_build_allocs != h.n_allocs) { rc = -3; msg = "packed engine does not match this build's layout"; }
@@ -1389,15 +1413,22 @@ extern "C" int ptts_lm_state_copy(ptts_lm_state *dst, const ptts_lm_state *src, 
 // Row `row` of dst <- the single sequence of src (B = 1): KV rows, offset and a BOS pending input.  Lets a batch
 // be assembled from utterances prefilled one by one with different prompt lengths (per-row offsets).
 extern "C" int ptts_lm_state_copy_row(ptts_lm_state *dst, int32_t row, const ptts_lm_state *src, void *stream) {
+  if (src && src->B != 1) return fail(-1, "copy_row: src must have batch 1 (use ptts_lm_state_copy_row_from)");
+  return ptts_lm_state_copy_row_from(dst, row, src, 0, stream);
+}
+extern "C" int ptts_lm_state_copy_row_from(ptts_lm_state *dst, int32_t row, const ptts_lm_state *src, int32_t src_row, void *stream) {
+  if (!dst || !src) return fail(-1, "null state");
   if (dst->e != src->e) return fail(-1, "states belong to different engines");
-  if (src->B != 1 || row < 0 || row >= dst->B) return fail(-1, "copy_row: src must have batch 1 and row must be in range");
+  if (src_row < 0 || src_row >= src->B || row < 0 || row >= dst->B) return fail(-1, "copy_row: row out of range");
   const ptts_config &c = dst->e->cfg;
   hipStream_t st = S(dst->e, stream);
-  const int T = src->h_off[0];
+  HIPCHK(hipSetDevice(dst->e->device));
+  const int T = src->h_off[src_row];
   if (T > dst->cap) return fail(-5, "copy_row: destination capacity too small");
   if (T) {
     const long total = (long)c.num_layers * 2 * c.num_heads * T * 16;
-    kv_copy_row_kernel<<<cdiv(total, 256), 256, 0, st>>>(dst->kv, src->kv, c.num_layers * 2, c.num_heads, T, src->cap, dst->cap, dst->B, row);
+    kv_copy_row_kernel<<<cdiv(total, 256), 256, 0, st>>>(dst->kv, src->kv, c.num_layers * 2, c.num_heads, T, src->cap, dst->cap, dst->B, row,
+                                                        src->B, src_row);
   }
   dst->h_off[row] = T;
   dst->h_active[row] = 1;
@@ -1492,11 +1523,14 @@ static bool flow_cluster_ok(const ptts_engine *e, const ptts_lm_state *s) {
   for (auto &r : e->res) if (!r.l0.bias || !r.l2.bias) return false;
   // every workgroup of the launch must be resident at once (they wait for each other) and a 9-wave workgroup fills a
   // CU: the grid is capped at opt_flow_max_cus workgroups (default 128: half the chip, so a codec kernel always has CUs left) (larger batches loop over row groups inside the kernel)
-  return FDF <= e->opt_flow_max_cus;
+  return FDF <= std::min(e->opt_flow_max_cus, e->n_cus);
 }
 // (re)allocates the per-state buffers whose size depends on the number of LSD steps; never called during capture
 static int ensure_flow(ptts_engine *e, ptts_lm_state *s, int steps, hipStream_t st) {
   if (steps <= s->flow_steps) return 0;
+  if (s->n_graphs > 0)
+    return fail(-1, "lsd_decode_steps grows beyond what this state's captured graphs were built for: destroy the graphs first "
+                    "(they hold the old AdaLN / exchange buffers)");
   const ptts_config &c = e->cfg;
   const int FDF = c.flow_dim / 16;
   s->flow_rt = 1;  // one cluster per 16 rows: rows are independent, the clusters' weight re-reads stay in L2
@@ -1531,7 +1565,7 @@ static void launch_flow_cluster(hipStream_t st, ptts_engine *e, ptts_lm_state *s
   const int FDF = c.flow_dim / 16, LF = c.ldim / 16;
   FlowArgs fa;
   memset(&fa, 0, sizeof fa);
-  fa.MT = s->MT; fa.M = s->B; fa.NG = s->flow_ng; fa.NCL = std::max(1, std::min(s->flow_ng, e->opt_flow_max_cus / FDF)); fa.FDF = FDF; fa.LF = LF; fa.AF = e->adaln.NT;
+  fa.MT = s->MT; fa.M = s->B; fa.NG = s->flow_ng; fa.NCL = std::max(1, std::min(s->flow_ng, std::min(e->opt_flow_max_cus, e->n_cus) / FDF)); fa.FDF = FDF; fa.LF = LF; fa.AF = e->adaln.NT;
   fa.depth = c.flow_depth; fa.steps = lsd_steps; fa.ldim = c.ldim;
   fa.w_in = e->input_proj.w; fa.b_in = e->input_proj.bias;
   for (int r = 0; r < c.flow_depth; ++r) {
@@ -1551,6 +1585,7 @@ static void launch_flow_cluster(hipStream_t st, ptts_engine *e, ptts_lm_state *s
   ProfScope ps(st, "flow_cluster@" + std::to_string((long)fa.NCL * FDF * FLOW_THREADS),
                lsd_steps * (wbytes + 4.0 * s->B * 16.0 * e->adaln.NT), flops);
   const int kpw = cdiv(std::max(FDF, LF), FLOW_WORKERS);
+  s->coop_wgs = std::max(s->coop_wgs, fa.NCL * FDF);
   launch_flow_rt<1>(st, fa, kpw);
 }
 
@@ -1560,6 +1595,7 @@ static void launch_flow_cluster(hipStream_t st, ptts_engine *e, ptts_lm_state *s
 static constexpr int kLmMaxWGs = 256;  // resident workgroups of one launch (one per CU)
 static bool lm_cluster_ok(const ptts_engine *e, const ptts_lm_state *s) {
   if (!e->opt_lm_cluster || !e->lm_table) return false;
+  if (e->cfg.d_model / 16 > std::min(kLmMaxWGs, e->n_cus)) return false;  // one cluster must be resident at once
   return (double)s->kv_plane() * 4.0 < 2.0e9;  // 32-bit buffer offsets into a K / V plane
 }
 static int ensure_lm_cluster(ptts_engine *e, ptts_lm_state *s, hipStream_t st) {
@@ -1577,7 +1613,8 @@ static void launch_lm_cluster(hipStream_t st, ptts_engine *e, ptts_lm_state *s, 
   LmArgs la;
   memset(&la, 0, sizeof la);
   la.MT = s->MT; la.M = s->B; la.NG = s->MT; la.DF = c.d_model / 16; la.FFF = c.ff_dim / 16; la.H = c.num_heads;
-  la.NCL = std::max(1, std::min(la.NG, kLmMaxWGs / la.DF));
+  la.NCL = std::max(1, std::min(la.NG, std::min(kLmMaxWGs, e->n_cus) / la.DF));
+  s->coop_wgs = std::max(s->coop_wgs, la.NCL * la.DF);
   la.L = c.num_layers; la.cap = s->cap;
   la.layers = e->lm_table; la.kv = s->kv; la.kv_plane = (long)s->kv_plane();
   la.offset = s->offset; la.freq = e->freq_lm; la.x = sc.x; la.exch = s->lexch; la.flags = s->lflags;
@@ -1591,27 +1628,58 @@ static void launch_lm_cluster(hipStream_t st, ptts_engine *e, ptts_lm_state *s, 
   lm_cluster_kernel<0><<<dim3(la.NCL * la.DF), dim3(FLOW_THREADS), 0, st>>>(la);
 }
 
-// Cooperative kernels (flow / transformer clusters) need all their workgroups resident; two of them running at the same
-// time on one GPU (two states stepped from two streams) could starve each other.  Every step that contains them is
-// therefore chained behind the previous such step of the same DEVICE with an event (GPU-side order, no host wait).
+// Cooperative kernels (flow / transformer clusters) need all their workgroups resident: a launch of W workgroups (one per
+// CU, see flow_cluster_ok) may share the GPU with other cooperative launches only while the SUM of their grids fits the
+// device - beyond that two half-resident grids could wait for each other.  Steps that contain such a launch therefore take
+// one of N = floor(CUs / W) per-device SLOTS: step k (in launch order, all states and streams of the device) waits on the GPU
+// for step k - N and records its slot's event when it ends.  N = 2 for the flow cluster's default 128 workgroups, so the
+// FlowLM steps of two states queued on two streams overlap (round 2 chained them all, lm || lm = 2.16x one alone); the
+// 256-workgroup transformer cluster gets N = 1, i.e. the old strict chain.  GPU-side order only, the host never waits.
+static constexpr int kCoopMaxSlots = 4;
+struct CoopSlots { hipEvent_t ev[kCoopMaxSlots] = {}; bool used[kCoopMaxSlots] = {}; unsigned long long next = 0; };
 static std::mutex g_coop_mu;
-static hipEvent_t g_coop_ev[64] = {};
+static CoopSlots g_coop[64];
 struct CoopGuard {
-  int dev;
+  CoopSlots *cs = nullptr;
   hipStream_t st;
-  bool on;
-  CoopGuard(int device, hipStream_t stream, bool enabled) : dev(device & 63), st(stream), on(enabled) {
-    if (!on) return;
+  int slot = 0, rc = 0;
+  // `wgs` = workgroups of the step's cooperative launch (0: none, the guard does nothing); `n_cus` = CUs of the device
+  CoopGuard(int device, hipStream_t stream, int wgs, int n_cus) : st(stream) {
+    if (wgs <= 0) return;
     g_coop_mu.lock();
-    if (!g_coop_ev[dev]) (void)hipEventCreateWithFlags(&g_coop_ev[dev], hipEventDisableTiming);
-    else (void)hipStreamWaitEvent(st, g_coop_ev[dev], 0);
+    cs = &g_coop[device & 63];
+    // the events belong to the device of the engine, whatever device the calling thread had current (a scheduler thread
+    // of an engine on cuda:N > 0): the callers have run hipSetDevice(e->device)
+    const int n = std::max(1, std::min(kCoopMaxSlots, n_cus / wgs));
+    slot = (int)(cs->next++ % (unsigned)n);
+    if (!cs->ev[slot] && hipEventCreateWithFlags(&cs->ev[slot], hipEventDisableTiming) != hipSuccess) { rc = -2; cs->ev[slot] = nullptr; return; }
+    // a launch that needs more than its share (n shrank: e.g. the transformer cluster after flow-only steps) waits for ALL slots
+    for (int i = 0; i < kCoopMaxSlots; ++i)
+      if (cs->ev[i] && cs->used[i] && (i == slot || i >= n))
+        if (hipStreamWaitEvent(st, cs->ev[i], 0) != hipSuccess) rc = -2;
   }
-  ~CoopGuard() {
-    if (!on) return;
-    if (g_coop_ev[dev]) (void)hipEventRecord(g_coop_ev[dev], st);
+  int finish() {  // call after the step is enqueued; returns < 0 when the chain could not be established
+    if (!cs) return 0;
+    if (cs->ev[slot]) {
+      if (hipEventRecord(cs->ev[slot], st) != hipSuccess) rc = -2;
+      else cs->used[slot] = true;
+    }
+    CoopSlots *c = cs;
+    cs = nullptr;
+    (void)c;
     g_coop_mu.unlock();
+    return rc;
   }
+  ~CoopGuard() { if (cs) { cs = nullptr; g_coop_mu.unlock(); } }
 };
+// CUs a stream may use (hipExtStreamCreateWithCUMask streams: the bits of its mask; else the whole device)
+static int stream_cu_count(hipStream_t st, int n_cus) {
+  uint32_t mask[16] = {};
+  if (!st || hipExtStreamGetCUMask(st, 16, mask) != hipSuccess) { (void)hipGetLastError(); return n_cus; }
+  int bits = 0;
+  for (uint32_t w : mask) bits += __builtin_popcount(w);
+  return bits > 0 ? std::min(bits, n_cus) : n_cus;
+}
 
 static void lm_layers(hipStream_t st, ptts_engine *e, ptts_lm_state *s, Scratch &sc, int M, int Tq, bool rope_done = false) {
   const ptts_config &c = e->cfg;
@@ -1664,6 +1732,21 @@ extern "C" int ptts_lm_prefill(ptts_engine *e, ptts_lm_state *s, const float *d_
   return 0;
 }
 
+// workgroups of the largest cooperative launch a decode step of this state contains (0: per-layer launches only)
+static int coop_wgs_of_step(const ptts_engine *e, const ptts_lm_state *s, int lsd_steps) {
+  int w = 0;
+  const ptts_config &c = e->cfg;
+  if (flow_cluster_ok(e, s) && lsd_steps <= s->flow_steps) {
+    const int FDF = c.flow_dim / 16;
+    w = std::max(1, std::min(s->flow_ng, std::min(e->opt_flow_max_cus, e->n_cus) / FDF)) * FDF;
+  }
+  if (lm_cluster_ok(e, s) && s->lexch) {
+    const int DF = c.d_model / 16;
+    w = std::max(w, std::max(1, std::min(s->MT, std::min(kLmMaxWGs, e->n_cus) / DF)) * DF);
+  }
+  return w;
+}
+
 static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, const float *d_latent_in,
                            const float *d_noise, int lsd_steps, float eos_thr, float *d_latent_out,
                            float *d_eos_logit, uint8_t *d_is_eos) {
@@ -1671,6 +1754,7 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
   bind_engine(e);
   const int B = s->B, MT = s->MT, D = c.d_model, FD = c.flow_dim, DF = D / 16, FDF = FD / 16, LF = c.ldim / 16;
   Scratch &sc = s->dec;
+  s->coop_wgs = 0;
   const float *tcomb = e->tcomb[lsd_steps];
   SITE("lm.prep");
   {
@@ -1770,8 +1854,13 @@ extern "C" int ptts_lm_decode_step(ptts_engine *e, ptts_lm_state *s, const float
   for (int b = 0; b < s->B; ++b)
     if (s->h_off[b] + 1 > s->cap) return fail(-5, "decode: KV cache capacity exceeded");
   {
-    CoopGuard guard(e->device, S(e, stream), e->opt_lm_cluster || e->opt_flow_cluster);
+    // grid of the cooperative launch this step will contain (the enqueue records the exact value in s->coop_wgs)
+    const int wgs = coop_wgs_of_step(e, s, lsd_steps);
+    if (wgs > stream_cu_count(S(e, stream), e->n_cus))
+      return fail(-1, "decode: the stream's CU mask is smaller than the cooperative flow launch (lower the flow_max_cus option)");
+    CoopGuard guard(e->device, S(e, stream), wgs, e->n_cus);
     CHK(lm_step_enqueue(S(e, stream), e, s, d_latent_in, d_noise, lsd_steps, eos_threshold, d_latent_out, d_eos_logit, d_is_eos));
+    if (guard.finish() < 0) return fail(-2, "decode: could not chain the cooperative launch behind its predecessor");
   }
   for (int b = 0; b < s->B; ++b) s->h_off[b] += s->h_active[b];
   HIPCHK(hipGetLastError());
@@ -2437,9 +2526,12 @@ extern "C" int ptts_graph_capture_lm_step(ptts_engine *e, ptts_lm_state *s, cons
   CHK(ensure_lm_cluster(e, s, e->stream));
   ptts_graph *g = new ptts_graph();
   g->lm = s;
-  CHK(capture(e, g, [&](hipStream_t st) {
+  const int rc = capture(e, g, [&](hipStream_t st) {
     return lm_step_enqueue(st, e, s, nullptr, d_noise, lsd_steps, eos_threshold, d_latent_out, d_eos_logit, d_is_eos);
-  }));
+  });
+  if (rc < 0) { g->lm = nullptr; ptts_graph_destroy(g); return rc; }
+  g->coop_wgs = s->coop_wgs;
+  s->n_graphs += 1;
   *out = g;
   return 0;
 }
@@ -2450,7 +2542,8 @@ extern "C" int ptts_graph_capture_mimi(ptts_engine *e, ptts_mimi_state *s, const
   HIPCHK(hipSetDevice(e->device));
   ptts_graph *g = new ptts_graph();
   g->mimi = s;
-  CHK(capture(e, g, [&](hipStream_t st) { return mimi_enqueue(st, e, s, d_latent, d_pcm); }));
+  const int rc = capture(e, g, [&](hipStream_t st) { return mimi_enqueue(st, e, s, d_latent, d_pcm); });
+  if (rc < 0) { g->mimi = nullptr; ptts_graph_destroy(g); return rc; }
   *out = g;
   return 0;
 }
@@ -2489,7 +2582,9 @@ extern "C" int ptts_graph_capture_pipelined(ptts_engine *e, ptts_lm_state *s, pt
   hipEventDestroy(fork);
   hipEventDestroy(join);
   hipStreamDestroy(side);
-  CHK(rc);
+  if (rc < 0) { g->lm = nullptr; g->mimi = nullptr; ptts_graph_destroy(g); return rc; }
+  g->coop_wgs = s->coop_wgs;
+  s->n_graphs += 1;
   *out = g;
   return 0;
 }
@@ -2497,13 +2592,20 @@ extern "C" int ptts_graph_capture_pipelined(ptts_engine *e, ptts_lm_state *s, pt
 extern "C" int ptts_graph_launch(ptts_graph *g, void *stream) {
   ptts_engine *e = g->lm ? g->lm->e : g->mimi->e;
   ENGINE_LOCK(e);
+  HIPCHK(hipSetDevice(e->device));  // the calling thread may have another device current (scheduler threads of cuda:N > 0)
   if (g->lm) {
     for (int b = 0; b < g->lm->B; ++b)
       if (g->lm->h_off[b] + 1 > g->lm->cap) return fail(-5, "decode: KV cache capacity exceeded");
   }
   {
-    CoopGuard guard(e->device, S(e, stream), g->lm != nullptr && (e->opt_lm_cluster || e->opt_flow_cluster));
+    if (g->coop_wgs > 0 && g->cu_checked != S(e, stream)) {
+      if (g->coop_wgs > stream_cu_count(S(e, stream), e->n_cus))
+        return fail(-1, "graph launch: the stream's CU mask is smaller than the cooperative launch captured in this graph");
+      g->cu_checked = S(e, stream);
+    }
+    CoopGuard guard(e->device, S(e, stream), g->coop_wgs, e->n_cus);
     HIPCHK(hipGraphLaunch(g->exec, S(e, stream)));
+    if (guard.finish() < 0) return fail(-2, "graph launch: could not chain the cooperative launch behind its predecessor");
   }
   if (g->lm) for (int b = 0; b < g->lm->B; ++b) g->lm->h_off[b] += g->lm->h_active[b];
   if (g->mimi) g->mimi->h_frame += 1;
@@ -2512,6 +2614,7 @@ extern "C" int ptts_graph_launch(ptts_graph *g, void *stream) {
 
 extern "C" void ptts_graph_destroy(ptts_graph *g) {
   if (!g) return;
+  if (g->lm && g->exec && g->lm->n_graphs > 0) g->lm->n_graphs -= 1;
   if (g->exec) hipGraphExecDestroy(g->exec);
   if (g->graph) hipGraphDestroy(g->graph);
   if (g->cap_stream) hipStreamDestroy(g->cap_stream);
@@ -2532,7 +2635,7 @@ extern "C" int ptts_set_option(ptts_engine *e, const char *key, int32_t value) {
     e->opt_codec_lds_target = value;
   }
   else if (k == "flow_max_cus") {
-    if (value < 8 || value > 256) return fail(-1, "flow_max_cus must be in [8, 256]");
+    if (value < 8 || value > e->n_cus) return fail(-1, "flow_max_cus must be in [8, CUs of the device = " + std::to_string(e->n_cus) + "]");
     e->opt_flow_max_cus = value;
   }
   else return fail(-1, "unknown option " + k);
@@ -2542,9 +2645,19 @@ extern "C" int ptts_lm_state_error(ptts_lm_state *s, void *stream) {
   if (!s) return fail(-1, "null state");
   int h = 0;
   hipStream_t st = S(s->e, stream);
+  HIPCHK(hipSetDevice(s->e->device));
   HIPCHK(hipMemcpyAsync(&h, s->ferr, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemsetAsync(s->ferr, 0, sizeof(int), st));  // read AND clear: one transient timeout is reported once
   HIPCHK(hipStreamSynchronize(st));
   return h != 0;
+}
+extern "C" int ptts_debug_set_error(ptts_lm_state *s, int32_t value, void *stream) {
+  if (!s) return fail(-1, "null state");
+  hipStream_t st = S(s->e, stream);
+  HIPCHK(hipSetDevice(s->e->device));
+  HIPCHK(hipMemsetAsync(s->ferr, value ? 1 : 0, 1, st));  // little endian: byte 0 = the word's low byte
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
 }
 // A stream whose kernels run on a subset of the CUs (hipExtStreamCreateWithCUMask): CUs [cu_lo, cu_hi) of EVERY XCD.
 // Measured on MI355X / ROCm 7.2 (tools/cu_mask_probe.py): mask bit i addresses CU i / 8 of XCD i % 8, a kernel runs

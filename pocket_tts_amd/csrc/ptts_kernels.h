@@ -454,12 +454,12 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
   // decode (K-split) tiles: as many fragments per round as the register file allows, so that a wave needs
   // few serialized HBM round trips for its cold weight stream
   // K-split (decode) tiles hold PTTS_KSPLIT_DIV times fewer fragments per round than the register file would allow.
-  // Measured (tools/ab_lib.sh, batch 64 pipelined): DIV 1 (253 VGPRs for the 2x2 tile) 0.935-0.939 ms per step, DIV 2 (173)
+  // Measured (tools/ab.sh lib, batch 64 pipelined): DIV 1 (253 VGPRs for the 2x2 tile) 0.935-0.939 ms per step, DIV 2 (173)
   // 0.905-0.910, DIV 4 (128) 0.920.  A FlowLM GEMM is ~1 wave per SIMD that mostly waits for its weights: at 253
   // registers it pins HALF of every SIMD's register file while resident and evicts the codec stream's waves; with half
   // the fragments in flight it is barely slower alone (batch 1: 0.358 -> 0.355 ms per step) and the codec keeps its occupancy.
   // The optimum is sharp and the same for every tile: the single-tile (1x1) configurations alone at 4 or at 1: 0.875 / 0.878
-  // against 0.846 (PTTS_KSPLIT_DIV1, tools/ab_libs.sh).
+  // against 0.846 (PTTS_KSPLIT_DIV1, tools/ab.sh lib).
 #ifndef PTTS_KSPLIT_DIV
 #define PTTS_KSPLIT_DIV 2
 #endif
@@ -1364,7 +1364,7 @@ struct AttnArgs {
 // v_permlane32_swap): lanes c, c + 16, c + 32, c + 48 end up with the max / sum of their four values.  The ds_bpermute
 // path of __shfl_xor costs an LDS round trip (> 100 cycles) per step, in the middle of every tile's dependent chain.
 // (inline asm: ROCm 7.2's clang returns the FIRST result of __builtin_amdgcn_permlane{16,32}_swap in both elements
-// of its result vector - tests/hip/xrow_test - so the builtin cannot be used; the s_nop covers the VALU-write ->
+// of its result vector - tests/hip/xrow_test.hip, run by tests/test_gpu_parity_r3.py - so the builtin cannot be used; the s_nop covers the VALU-write ->
 // permlane-swap hazard the compiler would otherwise pad)
 struct xrow_pair { float a, b; };
 __device__ __forceinline__ xrow_pair xrow_swap16(float x) {
@@ -1906,7 +1906,7 @@ __global__ void kv_export_kernel(float *dst, const float *Kc, const float *Vc, i
 // dst rows <- src rows (src batch 1 broadcasts), whole [L][2][B][H][cap][64] block, equal cap
 // one batch-1 state -> row `row` of a batch state: [planes][1][H][src_cap][64] -> [planes][B][H][dst_cap][64], T positions
 __global__ void kv_copy_row_kernel(float *dst, const float *src, int planes, int H, int T, int src_cap, int dst_cap,
-                                   int B, int row) {
+                                   int B, int row, int srcB = 1, int src_row = 0) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (plane, head, t, 16 float4)
   if (i >= (long)planes * H * T * 16) return;
   const int v = i & 15;
@@ -1914,7 +1914,7 @@ __global__ void kv_copy_row_kernel(float *dst, const float *src, int planes, int
   const int t = r % T; r /= T;
   const int h = r % H;
   const int pl = r / H;
-  const f32x4 x = *(const f32x4 *)(src + (((size_t)pl * H + h) * src_cap + t) * 64 + v * 4);
+  const f32x4 x = *(const f32x4 *)(src + ((((size_t)pl * srcB + src_row) * H + h) * src_cap + t) * 64 + v * 4);
   *(f32x4 *)(dst + ((((size_t)pl * B + row) * H + h) * dst_cap + t) * 64 + v * 4) = x;
 }
 

@@ -100,9 +100,9 @@ class LMState:
         e.sync()
         return out
 
-    def copy_row_from(self, row: int, src: "LMState"):
-        """row `row` <- the single sequence of `src` (batch 1); rows may have different lengths"""
-        _lib.check(self.engine.lib.ptts_lm_state_copy_row(self.handle, row, src.handle, self.engine._sp))
+    def copy_row_from(self, row: int, src: "LMState", src_row: int = 0):
+        """row `row` <- sequence `src_row` of `src`; rows may have different lengths"""
+        _lib.check(self.engine.lib.ptts_lm_state_copy_row_from(self.handle, row, src.handle, src_row, self.engine._sp))
 
     def copy_from(self, src: "LMState"):
         _lib.check(self.engine.lib.ptts_lm_state_copy(self.handle, src.handle, self.engine._sp))
@@ -511,6 +511,8 @@ class StepPipeline:
       of a forked graph do not run concurrently).
     """
 
+    NB_EVENTS = int(os.environ.get("PTTS_PIPE_NB", "4"))  # output-buffer ring depth of the "events" mode
+
     def __init__(self, eng: Engine, lm_state: LMState, mimi_state: MimiState, noise=None, lsd_steps: int = 1,
                  eos_threshold: float = -4.0, mode: str | None = None, pcm_i16: bool = False,
                  lm_stream: torch.cuda.Stream | None = None):
@@ -519,8 +521,9 @@ class StepPipeline:
         self.mode = mode or ("hostsync" if B <= 8 else "events")
         # ring of output buffers (latent -> codec input, EOS flags, PCM).  Throughput mode keeps 4 so that the FlowLM
         # stream may run up to 3 steps ahead of the codec stream (with 2 the two streams move in lock-step and every
-        # hiccup of one stalls the other); the latency modes need only 2.
-        self.nb = nb = int(os.environ.get("PTTS_PIPE_NB", "4")) if self.mode == "events" else 2
+        # hiccup of one stalls the other); the latency modes need only 2.  A host loop over the "events" mode must have
+        # read flag[t % nb] / pcm[t % nb] of step t - nb before it calls step() for step t.
+        self.nb = nb = self.NB_EVENTS if self.mode == "events" else 2
         self.lat = [torch.zeros(B, eng.ldim, device=dev) for _ in range(nb)]
         self.logit = [torch.empty(B, device=dev) for _ in range(nb)]
         self.flag = [torch.zeros(B, dtype=torch.uint8).pin_memory() for _ in range(nb)]  # EOS flags land on the host

@@ -29,6 +29,12 @@ from .weights import generate_state_dict
 
 logger = logging.getLogger(__name__)
 
+# Like the reference at import (tts_model.py:49).  Here it matters for another reason: the host loops of the batched paths
+# copy small PCM frames with CPU tensor ops; with ATen's intra-op pool sized to the machine (256 hardware threads on an
+# MI355X host, of which a container may own 16) every such op wakes an oversubscribed OpenMP team whose spinning workers
+# then starve the thread that feeds the GPU (measured: 7 ms per 491 KB frame copy, 5 ms per event wait; 10x the step time).
+torch.set_num_threads(1)
+
 DEFAULT_LANGUAGE = "english"
 DEFAULT_TEMPERATURE = 0.7
 DEFAULT_LSD_DECODE_STEPS = 1
@@ -206,13 +212,16 @@ class TTSModel:
         requires equal cache offsets across a batch: tts_model.py:491-492, transformer.py:12-13).
 
         `model_states`: one voice state or a list (one per text); `texts`: list of short texts (each must
-        fit one chunk of `MAX_TOKEN_PER_CHUNK` tokens; split longer texts first).  Every utterance is prefilled
-        on its own (voice + text lengths differ), placed in one row of a batch state, and all rows are decoded
-        in lock-step with per-row positions; per-row EOS bookkeeping follows tts_model.py:756-768.  With
-        temp == 0 each waveform equals the single-utterance result; with temp > 0 rows draw independent noise
-        (the reference's sequential use of the global generator cannot be reproduced across a batch).
-        Returns a list of fp32 CPU tensors."""
-        from .batching import eos_bookkeeping
+        fit one chunk of `MAX_TOKEN_PER_CHUNK` tokens; split longer texts first).  Utterances that share a voice
+        state and a token count are prefilled together as one batch (one GEMM pass per group, the voice's KV cloned
+        from its device-resident copy), every utterance then owns one row of a batch state, and all rows are decoded
+        in lock-step with per-row positions on the two-stream step pipeline (FlowLM step t+1 overlaps codec frame t).
+        The host never waits for the GPU inside the loop: the EOS flags and the PCM of a step land in pinned memory
+        and are read a few steps later, so a row runs at most `StepPipeline.nb` steps past its end (those frames are
+        dropped); per-row EOS bookkeeping follows tts_model.py:756-768.  With temp == 0 each waveform equals the
+        single-utterance result; with temp > 0 rows draw independent noise (the reference's sequential use of the
+        global generator cannot be reproduced across a batch).  Returns a list of fp32 CPU tensors."""
+        from .batching import eos_bookkeeping_rows
         from .engine import StepPipeline
 
         eng = self.engine
@@ -223,7 +232,6 @@ class TTSModel:
             raise ValueError("need one voice state per text")
         toks, gens, faes, t0s = [], [], [], []
         for text, ms_ in zip(texts, model_states):
-            prepared, guess = prepare_text_prompt(text, self.pad_with_spaces_for_short_inputs, self.remove_semicolons)
             # the reference tokenises the chunk text as split_into_best_sentences returns it (stripped)
             chunk = split_into_best_sentences(self.tokenizer.encode, self.tokenizer.sp, text, 10 ** 9,
                                               self.pad_with_spaces_for_short_inputs, self.remove_semicolons)
@@ -238,87 +246,154 @@ class TTSModel:
             toks.append(torch.tensor(ids, dtype=torch.long)[None, :])
             gens.append(estimate_max_gen_len(len(ids), self.config.mimi.frame_rate))
             faes.append(fae)
-            t0s.append(_state_current_end(ms_))
-        steps_max = max(gens)
-        cap = max(t + tk.shape[1] for t, tk in zip(t0s, toks)) + steps_max + 1
-        batch = eng.new_lm_state(B, cap)
-        ms = eng.new_mimi_state(B)
-        for b in range(B):  # per-utterance prefill (lengths differ), then into row b
-            one = eng.new_lm_state(1, t0s[b] + toks[b].shape[1])
-            _import_lm_state(eng, one, model_states[b], t0s[b])
-            eng.lm_prefill(one, eng.embed_text(toks[b]))
-            batch.copy_row_from(b, one)
-            eng.sync()
-            one.close()
-        use_noise = self.temp > 0
-        if use_noise:
-            batch.set_noise(self.temp, int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
-        pipe = StepPipeline(eng, batch, ms, None, self.lsd_decode_steps, float(self.eos_threshold), mode="hostsync")
-        eos_step = [None] * B
-        n_emit = [None] * B          # frames to keep for row b (decided when its loop would break)
-        chunks = [[] for _ in range(B)]
-        emitted = 0
+        # one device-resident copy per distinct voice state (no per-utterance import, no host sync on a hit)
+        voices = {}
+        for ms_ in model_states:
+            if id(ms_) not in voices:
+                voices[id(ms_)] = self._voice_acquire(ms_)
         try:
-            for step in range(steps_max):
-                pipe.lm_step_async()
-                flags = pipe.wait_flags(step)
-                for b in range(B):
-                    if n_emit[b] is None:
-                        eos_step[b], n_emit[b] = eos_bookkeeping(step, gens[b], faes[b], eos_step[b], bool(flags[b].item()))
-                if all(n is not None and n <= step for n in n_emit):
-                    break
-                # collect the previous frame before its pinned buffer is reused two frames later
-                if emitted >= 2:
-                    self._collect(pipe, emitted - 2, chunks, n_emit)
-                pipe.decode_async(step)
-                emitted += 1
-            for f in range(max(0, emitted - 2), emitted):
-                self._collect(pipe, f, chunks, n_emit)
+            t0s = [voices[id(ms_)][1] for ms_ in model_states]
+            steps_max = max(gens)
+            use_noise = self.temp > 0
+            need = max(t + tk.shape[1] for t, tk in zip(t0s, toks)) + steps_max + StepPipeline.NB_EVENTS + 2
+            cap = -(-need // 256) * 256
+            key = ("batch", B, cap, self.lsd_decode_steps, float(self.eos_threshold), use_noise)
+            ctx = self._ctx_cache.pop(key, None)
+            if ctx is None:
+                self._drop_batch_contexts(keep=1)
+                batch, ms = eng.new_lm_state(B, cap), eng.new_mimi_state(B)
+                if use_noise:
+                    batch.set_noise(self.temp, int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
+                pipe = StepPipeline(eng, batch, ms, None, self.lsd_decode_steps, float(self.eos_threshold), mode="events")
+                ctx = dict(st=batch, ms=ms, pipe=pipe)
+            batch, ms, pipe = ctx["st"], ctx["ms"], ctx["pipe"]
+            nb = pipe.nb
+            # group prefill: rows with the same voice and token count share one batched pass (lengths differ across groups)
+            groups: dict = {}
+            for b in range(B):
+                groups.setdefault((id(model_states[b]), toks[b].shape[1]), []).append(b)
+            tmp = []
+            for (vid, Tt), rows in groups.items():
+                voice_st, t_voice = voices[vid]
+                grp = eng.new_lm_state(len(rows), t_voice + Tt)
+                tmp.append(grp)
+                grp.copy_from(voice_st)
+                eng.lm_prefill(grp, eng.embed_text(torch.cat([toks[b] for b in rows], dim=0)))
+                for i, b in enumerate(rows):
+                    batch.copy_row_from(b, grp, i)
+            pipe.restart()  # zero codec carries, on the codec stream
+            gens_a, faes_a = np.asarray(gens), np.asarray(faes)
+            eos_step = np.full(B, -1, np.int64)
+            n_emit = np.full(B, -1, np.int64)  # frames to keep for row b (decided when its loop would break)
+            out = np.empty((B, steps_max, eng.frame_samples), np.float32)
+            flags_np = [f_.numpy() for f_ in pipe.flag]   # views of the pinned buffers the kernels write
+            pcm_np = [p_.numpy() for p_ in pipe.pcm]
+            t = collected = 0
+
+            def collect(f):
+                pipe.done_event(f).synchronize()  # codec frame f done => FlowLM step f done too
+                eos_bookkeeping_rows(f, gens_a, faes_a, eos_step, n_emit, flags_np[f % nb] != 0)
+                if f < steps_max:
+                    out[:, f] = pcm_np[f % nb]    # plain memcpy per row (numpy: no intra-op thread team)
+
+            while True:
+                decided = bool((n_emit >= 0).all())
+                if t - collected >= nb or (collected < t and pipe.done_event(collected).query()):
+                    collect(collected)  # before its pinned buffers are reused (mandatory), or as soon as it is ready
+                    collected += 1
+                    continue
+                if t >= steps_max or (decided and t >= int(n_emit.max())):
+                    if collected == t:
+                        break
+                    collect(collected)
+                    collected += 1
+                    continue
+                pipe.step()
+                t += 1
+            pipe.sync()
+            for g in tmp:
+                g.close()
+            if batch.error():  # a cooperative kernel gave up waiting for a peer: the audio of this batch is invalid
+                raise RuntimeError("libptts: a cooperative FlowLM kernel timed out; the audio of this batch is invalid")
+            self._ctx_cache[key] = ctx
         finally:
-            pipe.close()
-            batch.close()
-            ms.close()
-        out = []
+            for v in voices.values():
+                self._voice_release(v)
+        res = []
         for b in range(B):
-            n = n_emit[b] if n_emit[b] is not None else gens[b]
-            if eos_step[b] is None:
+            n = int(n_emit[b]) if n_emit[b] >= 0 else gens[b]
+            if eos_step[b] < 0:
                 logger.warning("Maximum generation length reached without EOS, this very often indicates an error.")
-            out.append(torch.cat(chunks[b][:n]) if n > 0 else torch.zeros(0))
-        return out
+            res.append(torch.from_numpy(out[b, :n].reshape(-1).copy()) if n > 0 else torch.zeros(0))
+        return res
 
-    @staticmethod
-    def _collect(pipe, frame, chunks, n_emit):
-        pipe.done_event(frame).synchronize()
-        pcm = pipe.pcm_of(frame)
-        for b in range(len(chunks)):
-            if n_emit[b] is None or frame < n_emit[b]:
-                chunks[b].append(pcm[b].clone())
+    def _drop_batch_contexts(self, keep: int = 0):
+        """cached batch contexts (state + graphs of `generate_audio_batch`) beyond the `keep` most recent are released"""
+        keys = [k for k in self._ctx_cache if k and k[0] == "batch"]
+        for k in keys[: max(0, len(keys) - keep)]:
+            c = self._ctx_cache.pop(k)
+            c["pipe"].close()
+            c["st"].close()
+            c["ms"].close()
 
-    def _voice_lm_state(self, model_state: dict, t_voice: int | None = None):
+    class _Voice:
+        """one device-resident voice: engine-layout KV of a voice-state dict + what identifies the dict's contents"""
+
+        __slots__ = ("sig", "st", "keep", "t_voice", "refs", "evicted")
+
+        def __init__(self, sig, st, keep, t_voice):
+            self.sig, self.st, self.keep, self.t_voice, self.refs, self.evicted = sig, st, keep, t_voice, 0, False
+
+        def __iter__(self):  # `voice_st, t_voice = entry`
+            return iter((self.st, self.t_voice))
+
+        def __getitem__(self, i):
+            return (self.st, self.t_voice)[i]
+
+    def _voice_acquire(self, model_state: dict, t_voice: int | None = None) -> "_Voice":
         """Device-resident engine-layout copy of a voice state dict, built on first use and reused while the dict's
-        tensors are unchanged (same storage, same in-place version); at most 8 voices stay resident.  Returns
-        `(LMState, t_voice)`; on a hit nothing touches the device (the reference reads `offset` with `.item()` on every
-        call, tts_model.py:412-414: a device sync when the state lives on the GPU)."""
+        tensors are unchanged (same storage, same in-place version); at most 8 voices stay resident.  On a hit nothing
+        touches the device (the reference reads `offset` with `.item()` on every call, tts_model.py:412-414: a device
+        sync when the state lives on the GPU).  The entry is REFERENCE-COUNTED: an eviction (more than 8 voices, or the
+        dict's tensors changed) by another thread - the cache is shared with ContinuousBatcher's scheduler thread - only
+        marks it; its `LMState` is destroyed by the last `_voice_release` (the clone kernels of a generation
+        that was still using the handle raced with its hipFree)."""
         with self._voice_lock:
             eng = self.engine
             sig = tuple((model_state[_layer_key(i)]["cache"].data_ptr(), model_state[_layer_key(i)]["cache"]._version,
                          model_state[_layer_key(i)]["offset"].data_ptr(), model_state[_layer_key(i)]["offset"]._version)
                         for i in range(eng.L))
             hit = self._voice_cache.get(id(model_state))
-            if hit is not None and hit[0] == sig:
-                return hit[1], hit[3]
+            if hit is not None and hit.sig == sig:
+                hit.refs += 1
+                return hit
             if hit is not None:
-                hit[1].close()
+                self._voice_evict(id(model_state))
             while len(self._voice_cache) >= 8:
-                self._voice_cache.pop(next(iter(self._voice_cache)))[1].close()
+                self._voice_evict(next(iter(self._voice_cache)))
             if t_voice is None:
                 t_voice = _state_current_end(model_state)
             vst = eng.new_lm_state(1, max(t_voice, 1))
             _import_lm_state(eng, vst, model_state, t_voice)
             # the entry keeps the source tensors alive, so a recycled id() / data_ptr() can never alias a cached voice
             keep = [model_state[_layer_key(i)][k] for i in range(eng.L) for k in ("cache", "offset")]
-            self._voice_cache[id(model_state)] = (sig, vst, keep, t_voice)
-            return vst, t_voice
+            ent = self._Voice(sig, vst, keep, t_voice)
+            ent.refs = 1
+            self._voice_cache[id(model_state)] = ent
+            return ent
+
+    def _voice_evict(self, key):
+        """caller holds the lock"""
+        ent = self._voice_cache.pop(key)
+        ent.evicted = True
+        if ent.refs == 0:
+            ent.st.close()
+
+    def _voice_release(self, ent: "_Voice"):
+        with self._voice_lock:
+            ent.refs -= 1
+            if ent.evicted and ent.refs == 0:
+                ent.st.close()
 
     def _draw_noise(self, out: torch.Tensor):
         """Same draws as the reference CPU path (flow_lm.py:131-137): torch's global CPU generator."""
@@ -333,7 +408,8 @@ class TTSModel:
         tokens = torch.tensor(self.tokenizer.encode(text), dtype=torch.long)[None, :]
         Tt = tokens.shape[1]
         max_gen_len = estimate_max_gen_len(Tt, self.config.mimi.frame_rate)
-        voice_st, t_voice = self._voice_lm_state(model_state)  # no device sync when the voice is already resident
+        voice = self._voice_acquire(model_state)  # no device sync when the voice is already resident
+        voice_st, t_voice = voice
         use_noise = self.temp > 0
         t_start = time.monotonic()
         # states, scratch and captured graphs are reused across chunks and calls (capacity rounded up)
@@ -411,6 +487,7 @@ class TTSModel:
                 model_state.update(_export_lm_state(eng, st, n))
         finally:
             pipe.sync()
+            self._voice_release(voice)
             self._ctx_cache[key] = ctx
         if st.error():  # a cooperative kernel gave up waiting for a peer (GPU oversubscribed beyond the library's contract)
             raise RuntimeError("libptts: a cooperative FlowLM kernel timed out; the audio of this chunk is invalid")

@@ -1,0 +1,126 @@
+"""Round-3 parity additions, through the C ABI on the GPU (`-m gpu`):
+
+  * the FULL-SIZE FlowLM (en100m) against the numpy oracle at the contexts `bench.py` runs (159 - 283 keys), batch 64
+    and batch 3: voice prefill of 126 positions + text prefill of 32 (the bench's shapes), decode steps at contexts
+    159-161, a further prefill up to 280 positions, decode steps at contexts 281-283.  Until this round the en100m model
+    met the oracle at <= 26 keys only; longer contexts were covered on `tiny` and through HIP-vs-HIP properties.
+    Reference: `StreamingMultiheadAttention.forward` transformer.py:135-158, `FlowLMModel.forward` flow_lm.py:96-139.
+  * the cooperative-kernel error word is read-and-clear: one transient timeout must not poison later chunks.
+
+Tolerances as in test_gpu_parity.py: latents / PCM max-abs <= 2e-4, EOS logits <= 1e-3, EOS decisions exact wherever the
+oracle's logit is further than 1e-3 from the threshold.
+"""
+
+import shutil
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import synth_weights
+from test_gpu_parity import ATOL, _maxerr, dev, get_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_long_context(B, graph):
+    from oracle import np_oracle as O
+
+    cfg, W = synth_weights("en100m")
+    eng = get_engine("en100m")
+    if B >= 16:
+        eng.tune(B)  # the tile table the bench uses for this batch (tuned shapes differ from the heuristic's)
+    Tv, Tt, n1, Tx, n2 = 126, 32, 3, 119, 3  # 126 + 32 = 158 -> steps at 159..161; + 119 = 280 -> steps at 281..283
+    rng = np.random.default_rng(1000 + B)
+    voice = (rng.standard_normal((B, Tv, eng.D)) * 0.1).astype(np.float32)   # bench.py: N(0, 1) * 0.1 conditioning
+    text = (rng.standard_normal((B, Tt, eng.D)) * 0.3).astype(np.float32)
+    extra = (rng.standard_normal((B, Tx, eng.D)) * 0.3).astype(np.float32)
+    noise = (rng.standard_normal((n1 + n2, B, eng.ldim)) * 0.7 ** 0.5).astype(np.float32)  # temp 0.7
+    cap = Tv + Tt + n1 + Tx + n2 + 1
+    lm, dec = O.FlowLM(cfg, W), O.MimiDecoder(cfg, W)
+    ost, oms = lm.init_state(B, cap), dec.init_state(B, n1 + n2)
+    st, ms = eng.new_lm_state(B, cap), eng.new_mimi_state(B)
+    lat, logit = torch.zeros(B, eng.ldim, device="cuda:0"), torch.zeros(B, device="cuda:0")
+    flag = torch.zeros(B, dtype=torch.uint8, device="cuda:0")
+    nz = torch.zeros(B, eng.ldim, device="cuda:0")
+    g = eng.capture_lm_step(st, nz, 1, -4.0, lat, logit, flag) if graph else None
+    try:
+        for e in (voice, text):
+            lm.prefill(ost, e)
+            eng.lm_prefill(st, dev(e))
+        xo = np.full((B, eng.ldim), np.nan, np.float32)
+        step = 0
+        for phase, n in ((0, n1), (1, n2)):
+            if phase == 1:
+                lm.prefill(ost, extra)
+                eng.lm_prefill(st, dev(extra))
+            for _ in range(n):
+                ctx = int(ost[0]["offset"]) + 1
+                xo, lo, eo = lm.decode_step(ost, xo, noise[step], 1, -4.0)
+                po = dec.decode(oms, xo)
+                if graph:
+                    nz.copy_(dev(noise[step]))
+                    torch.cuda.synchronize()
+                    eng.graph_launch(g)
+                    eng.sync()
+                    xg, lg, fg = lat, logit, flag
+                else:
+                    xg, lg, fg = eng.lm_decode_step(st, None, dev(noise[step]), 1, -4.0)
+                pg = eng.mimi_decode(ms, xg)
+                torch.cuda.synchronize()
+                assert _maxerr(xg.cpu().numpy(), xo) < ATOL, (ctx, "latent")
+                assert _maxerr(lg.cpu().numpy(), lo) < 1e-3, (ctx, "eos logit")
+                sure = np.abs(lo + 4.0) > 1e-3
+                assert np.array_equal((fg.cpu().numpy() > 0)[sure], eo[sure]), (ctx, "eos decision")
+                assert _maxerr(pg.cpu().numpy(), po) < ATOL, (ctx, "pcm")
+                step += 1
+        assert list(st.offsets()) == [Tv + Tt + n1 + Tx + n2] * B
+        assert not st.error()
+    finally:
+        if g is not None:
+            eng.graph_destroy(g)
+        st.close()
+        ms.close()
+
+
+def test_en100m_batch64_vs_oracle_at_bench_contexts():
+    """BASELINE config #3: batch 64, contexts 159-161 and 281-283, through the captured step graph the bench replays"""
+    _run_long_context(64, graph=True)
+
+
+def test_en100m_batch3_vs_oracle_at_bench_contexts():
+    """a partially filled row tile (3 of 16 rows), eager launches"""
+    _run_long_context(3, graph=False)
+
+
+def test_state_error_word_is_read_and_clear():
+    """`ptts_lm_state_error` returns the cooperative kernels' timeout word and clears it, so one transient timeout is
+    reported once instead of failing every later chunk on a cached state"""
+    from pocket_tts_amd import _lib
+
+    eng = get_engine("tiny")
+    st = eng.new_lm_state(2, 8)
+    try:
+        assert not st.error()
+        _lib.check(eng.lib.ptts_debug_set_error(st.handle, 1, eng._sp))
+        assert st.error()
+        assert not st.error()
+    finally:
+        st.close()
+
+
+def test_permlane_swap_inline_asm(tmp_path):
+    """tests/hip/xrow_test.hip: the inline-asm v_permlane16/32_swap used by the attention kernels' cross-row reductions
+    (ptts_kernels.h: xrow_swap16 / xrow_swap32) against the lane arithmetic worked out by hand; the program also prints
+    whether this compiler's builtin still returns its first result twice (the reason for the asm)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = Path(__file__).parent / "hip" / "xrow_test.hip"
+    exe = tmp_path / "xrow_test"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-value", "-o", str(exe), str(src)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    print(r.stdout)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])

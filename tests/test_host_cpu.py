@@ -90,6 +90,31 @@ def test_eos_bookkeeping_matches_reference_loop():
         assert n_emit == reference(flags, n, fae), (flags, n, fae)
 
 
+def test_eos_bookkeeping_rows_matches_scalar_version():
+    """the vectorised per-row bookkeeping of the batched paths (rows at different local steps, decisions read with a
+    lag) == the scalar `eos_bookkeeping`, row by row: same n_emit, same eos_step, decided at the same step"""
+    from pocket_tts_amd.batching import eos_bookkeeping, eos_bookkeeping_rows
+
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        B = int(rng.integers(1, 40))
+        gen, fae = rng.integers(1, 40, B), rng.integers(0, 6, B)
+        start = rng.integers(0, 7, B)                     # rows join at different global steps
+        flags = rng.random((60, B)) < 0.08
+        eos, emit = np.full(B, -1, np.int64), np.full(B, -1, np.int64)
+        want = [(None, None)] * B
+        for g in range(60):
+            rows = start <= g
+            eos_bookkeeping_rows(g - start, gen, fae, eos, emit, flags[g], rows)
+            for b in range(B):
+                if rows[b] and want[b][1] is None:
+                    want[b] = eos_bookkeeping(g - start[b], int(gen[b]), int(fae[b]), want[b][0], bool(flags[g, b]))
+                assert (emit[b] if emit[b] >= 0 else None) == want[b][1], (g, b)
+                if want[b][1] is None:
+                    assert (eos[b] if eos[b] >= 0 else None) == want[b][0], (g, b)
+        assert (emit >= 0).all()
+
+
 def test_pmc_tool_labels_match_the_profiler_labels():
     """tools/pmc_traffic.py turns rocprofv3's demangled kernel names into the labels bench.py's profiler uses
     (configuration + operand variant, '@<work-items>' appended by the caller), so that `roofline.traffic` finds them."""

@@ -3,7 +3,7 @@
 out=${1:-gpurun_out/matrix}; mkdir -p $out
 export PTTS_TUNE_CACHE=$PWD/profiles/tune_cache_mi355x.txt
 export PTTS_TUNE_CACHE_OUT=$PWD/$out/tune_additions.txt
-Q="--no-cpu-baseline --no-latency --no-profile"
+Q="--quick"
 python bench.py --preset config4 $Q > $out/config4_24l_b32.json 2> $out/config4.err
 python bench.py --preset int8 $Q > $out/int8.json 2> $out/int8.err
 python bench.py --preset bf16codec $Q > $out/bf16codec.json 2> $out/bf16codec.err
