@@ -24,7 +24,8 @@ the caller, tokenisation, voice clone and prefill inside the timed calls.
 per GPU, rendezvous on 127.0.0.1; under `torch.distributed.run` the ranks it is given are used.  Utterances are
 independent: each rank runs the same work on its own GPU, RCCL carries only the barriers and a few scalars, scaling is
 "weak".  Presets: `config4` = 24-layer model, 32 utterances per GPU (BASELINE.json configs[3], meant for --gpus 8);
-`b1` = batch 1; `int8` / `bf16codec` / `config5` = configs[4] (int8 LM weights, bf16 codec, both): separate lines, never the headline.
+`b1` = batch 1; `int8` / `bf16codec` / `config5` / `fp8codec` / `config5fp8` / `lmbf16` = configs[4] and the other reduced-precision
+formats (int8 LM weights, bf16 codec, fp8 codec convs, bf16 LM weights): separate lines, never the headline.
 
 Weights are synthetic (seed 0), data synthetic; fp32 end to end like the reference.  Rank 0 prints ONE JSON line.
 """
@@ -54,6 +55,9 @@ PRESETS = {
     "int8": dict(quantize=True),
     "bf16codec": dict(codec_bf16=True),
     "config5": dict(quantize=True, codec_bf16=True),
+    "fp8codec": dict(codec_fp8=True),
+    "config5fp8": dict(quantize=True, codec_fp8=True),   # BASELINE.json configs[4] as worded: int8 LM weights + fp8 codec convs
+    "lmbf16": dict(lm_bf16=True),
 }
 
 
@@ -76,6 +80,10 @@ def parse(argv=None):
                     help="BASELINE config #5: int8 weights for the FlowLM attention + FFN layers (not the headline)")
     ap.add_argument("--codec-bf16", action="store_true", default=None,
                     help="BASELINE config #5, second half: bf16 Mimi decoder, fp32 accumulate (not the headline)")
+    ap.add_argument("--codec-fp8", action="store_true", default=None,
+                    help="BASELINE config #5: SEANet convolutions on the fp8 MFMA, transformer bf16 (not the headline)")
+    ap.add_argument("--lm-bf16", action="store_true", default=None,
+                    help="bf16 weights + operands for the FlowLM Linear layers, fp32 accumulate (not the headline)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the cpu_baseline leg")
     ap.add_argument("--latency-trials", type=int, default=200)
     ap.add_argument("--no-api", action="store_true", help="skip the API-level batch throughput (api_batch)")
@@ -92,6 +100,8 @@ def parse(argv=None):
     args.config = args.config or "en100m"
     args.quantize = bool(args.quantize)
     args.codec_bf16 = bool(args.codec_bf16)
+    args.codec_fp8 = bool(args.codec_fp8)
+    args.lm_bf16 = bool(args.lm_bf16)
     return args
 
 
@@ -510,7 +520,8 @@ def main():
 
     cfg = named_config(args.config)
     W = generate_state_dict(cfg, 0)
-    groups = ({"attention", "ffn"} if args.quantize else set()) | ({"codec_bf16"} if args.codec_bf16 else set())
+    groups = (({"attention", "ffn"} if args.quantize else set()) | ({"codec_bf16"} if args.codec_bf16 else set())
+              | ({"codec_fp8"} if args.codec_fp8 else set()) | ({"lm_bf16"} if args.lm_bf16 else set()))
     eng = Engine(cfg, W, dev, quantize_groups=groups or None)
     job = Job(eng, args.batch, args, seed=rank)
 
@@ -594,7 +605,9 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": " + ".join(([("int8 weights (FlowLM attention+ffn), f32 activations/accumulate")] if args.quantize else [])
-                                + (["bf16 codec (weights+activations), f32 accumulate"] if args.codec_bf16 else [])) or "f32",
+                                + (["bf16 FlowLM Linear weights + operands, f32 accumulate"] if args.lm_bf16 else [])
+                                + (["bf16 codec (weights+activations), f32 accumulate"] if args.codec_bf16 else [])
+                                + (["fp8 e4m3 SEANet convs + bf16 Mimi transformer, f32 accumulate"] if args.codec_fp8 else [])) or "f32",
             "data": "synthetic (seeded weights, voice KV, token ids; fixed-length utterances, EOS stop disabled)",
             "config": {
                 "workload": f"{args.config}: batch {args.batch} concurrent utterances/GPU, voice KV {args.voice_len} + "
@@ -616,7 +629,10 @@ def main():
         # whole-step bounds at the contexts actually timed (SURVEY 8d bytes_step / flops formulas)
         bytes_step = (eng.lm_weight_bytes() + eng.mimi_weight_bytes()
                       + args.batch * (8 * L * ctx * 1024 + 2.18e6 + 68e3))
-        lm_mac = eng.lm_weight_bytes() / (1.0 if args.quantize else 4.0)  # one MAC per weight and row (int8: ~1 B/weight)
+        t_, f_ = cfg.flow_lm.transformer, cfg.flow_lm.flow   # one MAC per weight and row, whatever the weight format
+        d_, ff_, ld_ = t_.d_model, t_.d_model * t_.hidden_scale, cfg.mimi.quantizer.dimension
+        lm_mac = (L * (4 * d_ * d_ + 2 * d_ * ff_) + ld_ * d_ + d_ * (f_.dim + 1) + f_.dim * (3 * f_.dim * f_.depth + 2 * f_.dim)
+                  + ld_ * f_.dim + f_.depth * 2 * f_.dim * f_.dim + f_.dim * ld_)
         flops_step = 2.0 * args.batch * (lm_mac + 2 * L * ctx * 1024 + MIMI_MAC_PER_FRAME)
         step_s = wall / steps_timed
         out["step_roofline"] = {

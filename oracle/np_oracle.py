@@ -567,14 +567,16 @@ def elu_fast(x):
     return np.where(x > 0, x, np.exp(np.minimum(x, F32(0.0))) - F32(1.0)).astype(F32)
 
 
-def lnfold_linear_bf16(x, w, g, beta, bias, eps):
-    """LayerNorm folded into the following Linear, bf16 weights (ptts_bf16.h PRE_LNFOLD): x holds bf16 values"""
+def lnfold_linear_bf16(x, w, g, beta, bias, eps, stats_from=None):
+    """LayerNorm folded into the following Linear, bf16 weights (ptts_bf16.h / gemm_kernel<.., WF = 2> PRE_LNFOLD): x holds
+    bf16 values; `stats_from`: the fp32 tensor the row statistics are taken from when the operand is rounded on load"""
     wr = bf16_round(w * g[None, :])
     s = wr.sum(axis=1, dtype=F32)
     c = (w @ beta + (bias if bias is not None else F32(0))).astype(F32)
     K = x.shape[-1]
-    mu = x.sum(axis=-1, dtype=F32) / F32(K)
-    var = np.maximum((x * x).sum(axis=-1, dtype=F32) / F32(K) - mu * mu, F32(0))
+    xs = x if stats_from is None else stats_from
+    mu = xs.sum(axis=-1, dtype=F32) / F32(K)
+    var = np.maximum((xs * xs).sum(axis=-1, dtype=F32) / F32(K) - mu * mu, F32(0))
     rs = F32(1.0) / np.sqrt(var + F32(eps))
     return (((x @ wr.T) - mu[..., None] * s) * rs[..., None] + c).astype(F32)
 
@@ -625,3 +627,31 @@ class MimiDecoderBF16(MimiDecoder):
             if taps is not None:
                 taps[f"seanet{idx}"] = x.copy()
         return x[:, 0, :]
+
+
+# --------------------------------------------------------------------------------------------------
+# bf16 LM weights (PTTS_LM_BF16): rounding model of the build's FlowLM with bf16 Linear weights.  The four
+# Linear layers of every transformer layer (in_proj, out_proj, linear1, linear2: the reference's quantisation groups,
+# quantization.py:21,91-128) multiply bf16 weights with activation operands rounded to bf16 ON LOAD; the residual stream,
+# the LayerNorm statistics (taken from the fp32 values), q / k / v, the KV cache, attention, GELU, accumulation and the
+# whole flow head stay fp32.  No reference counterpart (parity with the reference unpinned); pins the HIP path to this
+# stated arithmetic.
+class FlowLMBF16(FlowLM):
+    def backbone(self, state, text_emb, seq, taps=None):
+        W = self.W
+        seq = np.where(np.isnan(seq), W["flow_lm.bos_emb"], seq).astype(F32)
+        x = linear(seq, W["flow_lm.input_linear.weight"])
+        x = np.concatenate([text_emb.astype(F32), x], axis=1)
+        T = x.shape[1]
+        for i in range(self.L):
+            p = f"flow_lm.transformer.layers.{i}"
+            proj = lnfold_linear_bf16(bf16_round(x), W[p + ".self_attn.in_proj.weight"], W[p + ".norm1.weight"],
+                                      W[p + ".norm1.bias"], None, 1e-5, stats_from=x)
+            ao = attention_core(proj, state[i], self.H, None, self.max_period)
+            x = (x + linear(bf16_round(ao), bf16_round(W[p + ".self_attn.out_proj.weight"]))).astype(F32)
+            f = lnfold_linear_bf16(bf16_round(x), W[p + ".linear1.weight"], W[p + ".norm2.weight"], W[p + ".norm2.bias"],
+                                   None, 1e-5, stats_from=x)
+            x = (x + linear(bf16_round(gelu(f)), bf16_round(W[p + ".linear2.weight"]))).astype(F32)
+        for st in state:
+            st["offset"] += T
+        return layer_norm(x, W["flow_lm.out_norm.weight"], W["flow_lm.out_norm.bias"], 1e-5)

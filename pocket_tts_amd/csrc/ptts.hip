@@ -4,6 +4,7 @@
 #include "ptts_flow.h"
 #include "ptts_bf16.h"
 #include "ptts_lm.h"
+#include "ptts_ext.h"
 
 #include <algorithm>
 #include <array>
@@ -70,10 +71,15 @@ struct Lin {  // one packed weight matrix
   // int8 weight-only variant (PTTS_QUANT_*): wq replaces w; ln_g = the LayerNorm gain applied to x on load
   uint8_t *wq = nullptr;
   float *wscale = nullptr, *ln_g = nullptr;
+  // bf16 weight variant of a FlowLM Linear (PTTS_LM_BF16): replaces w; packed [NT][KF/2][64][8] (GemmArgs::wfmt == 2)
+  void *wb16 = nullptr;
   // bf16 twin for the reduced-precision codec path (PTTS_CODEC_BF16): packed [NT][ntaps * C/32][64][8], ln_s from the rounded image
   __bf16 *wh = nullptr;
   float *ln_s_h = nullptr;
-  size_t bytes() const { return wq ? (size_t)NT * KF * 256 + (size_t)NT * 64 : (size_t)NT * KF * 1024; }
+  // e4m3 twin of a SEANet conv for the fp8 path (PTTS_CODEC_FP8): packed [NT][ntaps * C/32][64][8 bytes] + per-channel scale
+  void *wf8 = nullptr;
+  float *wscale8 = nullptr;
+  size_t bytes() const { return wq ? (size_t)NT * KF * 256 + (size_t)NT * 64 : wb16 ? (size_t)NT * KF * 512 : (size_t)NT * KF * 1024; }
 };
 
 struct TrLayer {
@@ -112,6 +118,13 @@ struct ptts_engine {
   float *conv_last_w = nullptr, *conv_last_b = nullptr;  // plain checkpoint tensors (bf16 path's last conv)
   bool codec_bf16 = false;
   int64_t mimi_bytes_h = 0;
+  // fp8 SEANet convolutions: static activation scales (device copy lives in an engine allocation, so packed-engine files
+  // carry it; f8s is its host mirror).  Index: 0 = conv0 output, 1 + 3 i = convtr_i output (ELU'd), 2 + 3 i = hidden
+  // activation of residual block i, 3 + 3 i = output of block i (i < 2: the next transposed conv's input)
+  bool codec_fp8 = false;
+  float *d_f8s = nullptr;
+  float f8s[16] = {};
+  int64_t mimi_bytes_f8 = 0;
   int ring = 0;
   // voice-prompt encode path (SEANet encoder, encoder transformer, downsample, speaker projection)
   bool has_encoder = false;
@@ -269,8 +282,11 @@ struct PackPart { std::string w, b; int N; };
 // packs one or several [N_i][C][ntaps] matrices (stacked along N) into one Lin
 static int pack_lin(ptts_engine *e, Lin *L, const std::vector<PackPart> &parts, int C, int ntaps, int mode = 0,
                     int cout = 0, int stride = 0, const std::string &ln_w = "", const std::string &ln_b = "",
-                    int creal = 0, bool q8 = false) {
+                    int creal = 0, int wfmt = 0) {
+  const bool q8 = wfmt == 1, b16 = wfmt == 2;
   if (C % 16) return fail(-4, "channel count must be a multiple of 16: " + parts[0].w);
+  if (b16 && (parts.size() != 1 || mode != 0 || ntaps != 1 || (C / 16) % 2))
+    return fail(-4, "bf16 LM weights need a single Linear matrix with in_features % 32 == 0: " + parts[0].w);
   if (q8 && (parts.size() != 1 || mode != 0 || ntaps != 1 || (C / 16) % 4))
     return fail(-4, "int8 weights need a single Linear matrix with in_features % 64 == 0: " + parts[0].w);
   int ntot = 0;
@@ -349,6 +365,17 @@ static int pack_lin(ptts_engine *e, Lin *L, const std::vector<PackPart> &parts, 
     HIPCHK(hipFree(L->w));
     L->w = nullptr;
   }
+  if (b16) {
+    // bf16 image from the fp32 one (LayerNorm gain already multiplied in); the fold vector s comes from the ROUNDED rows
+    CHK(dalloc(e, &L->wb16, (size_t)L->NT * L->KF * 512));
+    pack_weight_b16(e->stream, L->w, L->wb16, gam ? L->ln_s : nullptr, L->NT, L->KF);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->allocs.erase(std::remove(e->allocs.begin(), e->allocs.end(), (void *)L->w), e->allocs.end());
+    e->alloc_bytes.erase((void *)L->w);
+    HIPCHK(hipFree(L->w));
+    L->w = nullptr;
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -381,7 +408,8 @@ static int pack_lin_h(ptts_engine *e, Lin *L, const std::string &wname, int N, i
 }
 
 static int pack_tr_layer(ptts_engine *e, TrLayer *T, const std::string &p, int d, int ff, bool ls, int quant = 0) {
-  const bool qa = quant & PTTS_QUANT_ATTENTION, qf = quant & PTTS_QUANT_FFN;
+  const int qa = (quant & PTTS_LM_BF16) ? 2 : (quant & PTTS_QUANT_ATTENTION) ? 1 : 0;
+  const int qf = (quant & PTTS_LM_BF16) ? 2 : (quant & PTTS_QUANT_FFN) ? 1 : 0;
   CHK(copy_vec(e, p + ".norm1.weight", d, &T->ln1_w));
   CHK(copy_vec(e, p + ".norm1.bias", d, &T->ln1_b));
   CHK(copy_vec(e, p + ".norm2.weight", d, &T->ln2_w));
@@ -504,9 +532,12 @@ static bool q8_cfg(int cfg) { return cfg == 0 || cfg == 1 || cfg == 2 || cfg == 
 
 static bool cfg_valid(int cfg, const GemmArgs &a, int pre) {
   const int *s = kCfgShape[cfg];
-  if (a.Wq) {  // whole groups of four k-fragments per wave
+  if (a.wfmt) {  // whole groups of four (int8) / two (bf16) k-fragments per wave
     if (!q8_cfg(cfg) || (pre != PRE_NONE && pre != PRE_LNFOLD)) return false;
-    if (a.KF % (4 * s[2])) return false;
+    // bf16 weights: the 8-wave single-tile configuration is excluded - its bf16 instantiation produced NaNs on the GPU
+    // (gpurun_out/r3 debug run, every shape) while the 4-wave K-split and the 2-D tilings are exact; not understood yet
+    if (a.wfmt == 2 && cfg == 0) return false;
+    if (a.KF % ((a.wfmt == 1 ? 4 : 2) * s[2])) return false;
   }
   if (s[2] == 0) {  // LDS-staged: two k-fragments per stage, plain or LN-folded operand only
     if (a.KF % 2 || (pre != PRE_NONE && pre != PRE_LNFOLD)) return false;
@@ -533,7 +564,11 @@ static int swz_for(int cfg, const GemmArgs &a) {
 static void launch_by_cfg(hipStream_t st, const GemmArgs &a_in, int pre, int cfg) {
   GemmArgs a = a_in;
   a.swz = swz_for(cfg, a);
-  if (a.Wq) {
+  if (a.wfmt == 2) {
+    launch_gemm_b16(st, a, pre, cfg, 0);
+    return;
+  }
+  if (a.wfmt == 1) {
     switch (cfg) {
       case 0: launch_cfg_q8<1, 1, 8, 1, 1>(st, a, pre); break;
       case 1: launch_cfg_q8<1, 2, 4, 1, 1>(st, a, pre); break;
@@ -586,7 +621,7 @@ static thread_local const float *g_zeros = nullptr;  // both set by the entry po
 static thread_local int g_krot = 1;
 
 static TuneKey tune_key(const GemmArgs &a, int pre) {
-  return TuneKey{a.NT, a.KF, a.CF, a.ntaps, a.MT, a.epi, pre, a.act, a.xstride, a.halo_mode, a.Yraw ? 1 : 0, a.R ? 1 : 0, a.Wq ? 1 : 0};
+  return TuneKey{a.NT, a.KF, a.CF, a.ntaps, a.MT, a.epi, pre, a.act, a.xstride, a.halo_mode, a.Yraw ? 1 : 0, a.R ? 1 : 0, a.wfmt};
 }
 
 // Evicts L2 and the Infinity Cache by READING a large buffer (a write flush would leave dirty lines whose
@@ -679,8 +714,9 @@ static void launch_gemm(hipStream_t st, const GemmArgs &a_in, int pre) {
       if (f[0] == a.NT && f[1] == a.MT && f[2] >= 0 && f[2] < kNumCfg && cfg_valid(f[2], a, pre)) cfg = f[2];
   }
   if (cfg < 0 || !cfg_valid(cfg, a, pre)) cfg = pick_cfg(a);
-  if (a.Wq && !cfg_valid(cfg, a, pre)) cfg = 3;
-  if (a.Wq) bytes -= 3.0 * N * K;  // one byte per weight
+  if (a.wfmt && !cfg_valid(cfg, a, pre)) cfg = (a.wfmt == 2 && !cfg_valid(3, a, pre) && cfg_valid(11, a, pre)) ? 11 : 3;
+  if (a.wfmt == 1) bytes -= 3.0 * N * K;  // one byte per weight
+  if (a.wfmt == 2) bytes -= 2.0 * N * K;  // two
   // label = configuration + operand variant + "@<work-items>" (what rocprofv3 reports as Grid_Size), so that the
   // launches of one label are GEMMs of one grid, i.e. of one (NT, MT) shape class
   const int *sh = kCfgShape[cfg];
@@ -688,7 +724,7 @@ static void launch_gemm(hipStream_t st, const GemmArgs &a_in, int pre) {
                               : (long)cdiv(a.NT, sh[0] * sh[3]) * cdiv(a.MT, sh[1] * sh[4]);
   const long threads = wgs * (sh[2] == 0 ? 256 : 64 * sh[2] * sh[3] * sh[4]);
   ProfScope ps(st, std::string(kCfgName[cfg]) + (pre == PRE_NONE ? "" : pre == PRE_LNFOLD ? "+ln" : pre == PRE_LNMOD ? "+lnmod" : "+addsilu") +
-                       (a.Wq ? "+q8" : "") + "@" + std::to_string(threads), bytes, 2.0 * M * N * K);
+ (a.wfmt == 1 ? "+q8" : a.wfmt == 2 ? "+b16" : "") + "@" + std::to_string(threads), bytes, 2.0 * M * N * K);
   launch_by_cfg(st, a, pre, cfg);
 }
 
@@ -720,7 +756,8 @@ static GemmArgs mk_gemm(const Lin &L, const float *X, int XF, int MT, int M) {
   GemmArgs a;
   memset(&a, 0, sizeof(a));
   a.W = L.w;
-  a.Wq = L.wq;
+  a.Wq = L.wq ? L.wq : (const uint8_t *)L.wb16;
+  a.wfmt = L.wq ? 1 : L.wb16 ? 2 : 0;
   a.wscale = L.wscale;
   a.ln_g = L.ln_g;
   a.bias = L.bias;
@@ -882,6 +919,8 @@ static int seanet_check(const ptts_config &c) {
 }
 
 static int build_engine(ptts_engine *e, const ptts_tensor *tensors, int32_t n);
+static int build_fp8_codec(ptts_engine *e);
+static int sync_host_tables(ptts_engine *e);
 
 // device properties + the option defaults from the environment: shared by ptts_create_ex and ptts_create_from_file
 static int init_engine_options(ptts_engine *e, int device) {
@@ -983,7 +1022,7 @@ static int build_engine(ptts_engine *e, const ptts_tensor *tensors, int32_t n) {
     // head), linear1 at most 4 column tiles per workgroup
     const int DF = D / 16, FFF = c.ff_dim / 16;
     bool ok = DF <= 64 && DF % 4 == 0 && c.num_heads * 4 == DF && FFF % DF == 0 && FFF / DF <= 4 && c.num_layers <= 64;
-    for (auto &L : e->lm) ok = ok && !L.qkv.wq && !L.out.wq && !L.ff1.wq && !L.ff2.wq && !L.ls1 && !L.ls2 && L.qkv.ln_s && L.ff1.ln_s;
+    for (auto &L : e->lm) ok = ok && L.qkv.w && L.out.w && L.ff1.w && L.ff2.w && !L.ls1 && !L.ls2 && L.qkv.ln_s && L.ff1.ln_s;
     if (ok) {
       std::vector<LmLayerP> h(c.num_layers);
       for (int l = 0; l < c.num_layers; ++l) {
@@ -1027,7 +1066,7 @@ static int build_engine(ptts_engine *e, const ptts_tensor *tensors, int32_t n) {
     CHK(pack_lin(e, &e->conv_last, {{m + ".conv.weight", m + ".conv.bias", 1}}, nf, c.last_kernel_size));
   }
   CHK(dallocT(e, &e->zeros, 64));
-  if (e->quant_flags & PTTS_CODEC_BF16) {
+  if (e->quant_flags & (PTTS_CODEC_BF16 | PTTS_CODEC_FP8)) {
     // bf16 images of every codec GEMM (reference modules: mimi_transformer.py:12-54, seanet.py:141-180, conv.py:93-163)
     for (int l = 0; l < c.m_layers; ++l) {
       const std::string q = "mimi.decoder_transformer.transformer.layers." + std::to_string(l);
@@ -1054,6 +1093,7 @@ static int build_engine(ptts_engine *e, const ptts_tensor *tensors, int32_t n) {
     e->codec_bf16 = true;
     e->mimi_bytes_h += (int64_t)C * c.ldim * 4;
   }
+  if (e->quant_flags & PTTS_CODEC_FP8) CHK(build_fp8_codec(e));
   if (e->blob_dummy ? e->blob_has_encoder != 0
                     : (e->tmap.count("mimi.encoder.model.0.conv.weight") && e->tmap.count("flow_lm.speaker_proj_weight"))) {
     // reference mimi.py:96-119, seanet.py:63-104, resample.py:7-29, tts_model.py:379-388
@@ -1087,6 +1127,92 @@ static int build_engine(ptts_engine *e, const ptts_tensor *tensors, int32_t n) {
   HIPCHK(hipStreamSynchronize(e->stream));
   e->tmap.clear();
   e->n_build_allocs = e->allocs.size();
+  return sync_host_tables(e);
+}
+
+// PTTS_CODEC_FP8: e4m3 images of the SEANet convolutions that run on the fp8 MFMA, and the static activation scales from a
+// calibration run of the bf16 codec (8 sequences x 6 frames of N(0, 1) latents; scale = 2 x amax / 448, saturating).
+__global__ void calib_latent_kernel(float *lat, int n, unsigned frame) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) lat[i] = counter_normal(0x5EEDull, frame, (unsigned)i);
+}
+static int mimi_enqueue_h(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, const float *d_latent, float *d_pcm);
+static int build_fp8_codec(ptts_engine *e) {
+  const ptts_config &c = e->cfg;
+  const int nf = c.n_filters;
+  hipStream_t st = e->stream;
+  int mult = 8, idx = 1;
+  e->mimi_bytes_f8 = e->mimi_bytes_h;
+  for (int i = 0; i < 3; ++i) {
+    const int cin = mult * nf, cout = cin / 2, sr = c.ratios[i], hid = cout / c.compress;
+    if (cin % 32 || cout % 32 || hid % 32) return fail(-4, "fp8 codec path: channel counts must be multiples of 32");
+    struct Job { Lin *L; std::string name; int N, C, ntaps, mode, cout, stride; };
+    const std::string r = "mimi.decoder.model." + std::to_string(idx + 2);
+    const Job jobs[3] = {{&e->convtr[i], "mimi.decoder.model." + std::to_string(idx + 1) + ".convtr.weight", sr * cout, cin, 2, 1, cout, sr},
+                         {&e->res_a[i], r + ".block.1.conv.weight", hid, cout, c.res_kernel_size, 0, 0, 0},
+                         {&e->res_b[i], r + ".block.3.conv.weight", cout, hid, 1, 0, 0, 0}};
+    for (const Job &j : jobs) {
+      int err = 0;
+      const ptts_tensor *t = find_tensor(e, j.name, -1, &err);
+      if (!t) return err;
+      const size_t bytes = (size_t)j.L->NT * (j.C / 32) * j.ntaps * 512;
+      CHK(dalloc(e, &j.L->wf8, bytes));
+      CHK(dallocT(e, &j.L->wscale8, (size_t)j.L->NT * 16));
+      pack_weight_f8(st, t->d_data, j.L->wf8, j.L->wscale8, j.N, j.C, j.ntaps, j.mode, j.cout, j.stride);
+      HIPCHK(hipGetLastError());
+      e->mimi_bytes_f8 += (int64_t)bytes - 2 * (int64_t)bytes;  // e4m3 instead of bf16 for this matrix
+    }
+    idx += 3;
+    mult /= 2;
+  }
+  CHK(dallocT(e, &e->d_f8s, 16));
+  // ---- calibration on the bf16 path
+  const int B = 8, frames = 6;
+  ptts_mimi_state *ms = nullptr;
+  CHK(ptts_mimi_state_create(e, B, &ms));
+  float *lat = nullptr, *amax = nullptr;
+  int rc = 0;
+  if (hipMalloc((void **)&lat, (size_t)B * c.ldim * 4) != hipSuccess || hipMalloc((void **)&amax, 64) != hipSuccess) rc = fail(-2, "hipMalloc (fp8 calibration)");
+  if (rc == 0) {
+    (void)hipMemsetAsync(amax, 0, 64, st);
+    for (int f = 0; f < frames && rc == 0; ++f) {
+      calib_latent_kernel<<<cdiv(B * c.ldim, 256), 256, 0, st>>>(lat, B * c.ldim, (unsigned)f);
+      rc = mimi_enqueue_h(st, e, ms, lat, nullptr);
+      ms->h_frame += 1;
+      // both parity halves hold bf16 data in their first half (see mimi_enqueue_h); scan them after every frame
+      auto scan = [&](const float *buf, long stride, int slot) {
+        for (int par = 0; par < 2; ++par) amax_bf16(st, (const char *)buf + (size_t)par * stride * 4, stride, amax + slot);
+      };
+      scan(ms->a0, ms->a0_stride, 0);
+      for (int i = 0; i < 3; ++i) {
+        scan(ms->cbuf[i], ms->c_stride[i], 1 + 3 * i);
+        amax_bf16(st, ms->rbuf[i], (long)B * (ms->rows[i + 1] / 16) * 256 * ((8 >> i) * nf / 2 / c.compress / 16), amax + 2 + 3 * i);
+        if (i < 2) scan(ms->sbuf[i], ms->s_stride[i], 3 + 3 * i);
+      }
+    }
+  }
+  float h[16] = {};
+  if (rc == 0 && (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(h, amax, 64, hipMemcpyDeviceToHost) != hipSuccess)) rc = fail(-2, "fp8 calibration failed");
+  if (rc == 0) {
+    for (float &v : h) v = v > 0.f ? 2.0f * v / 448.0f : 1.0f;
+    if (hipMemcpy(e->d_f8s, h, 64, hipMemcpyHostToDevice) != hipSuccess) rc = fail(-2, "hipMemcpy (fp8 scales)");
+  }
+  if (lat) (void)hipFree(lat);
+  if (amax) (void)hipFree(amax);
+  ptts_mimi_state_destroy(ms);
+  CHK(rc);
+  e->codec_fp8 = true;
+  return 0;
+}
+
+// host mirrors of small device tables (after build_engine and again after a packed file has replaced the device images)
+static int sync_host_tables(ptts_engine *e) {
+  if (e->codec_fp8) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(e->f8s, e->d_f8s, sizeof(e->f8s), hipMemcpyDeviceToHost));
+    for (float &v : e->f8s)
+      if (!(v > 0.f)) v = 1.0f;
+  }
   return 0;
 }
 
@@ -1181,6 +1307,7 @@ extern "C" int ptts_create_from_file(const char *path, int32_t device, ptts_engi
   }
   fclose(f);
   (void)hipFree(zeros);
+  if (rc == 0 && sync_host_tables(e) < 0) { rc = -2; msg = g_err; }
   if (rc < 0) {
     ptts_destroy(e);
     return fail(rc, msg);
@@ -1969,18 +2096,23 @@ extern "C" int ptts_mimi_state_reset_row(ptts_mimi_state *s, int32_t row, void *
   if (!s || row < 0 || row >= s->B) return fail(-1, "reset_row: row out of range");
   hipStream_t st = S(s->e, stream);
   const int CF = s->e->cfg.m_dim / 16;
-  const int div = s->e->codec_bf16 ? 2 : 1;  // bf16 activations: a sequence's block is half as many floats, at half the offset
+  // bytes per element of each double-buffered conv input: fp32 codec 4; bf16 codec 2; fp8 codec: 1 for the fp8 conv inputs
+  // (a0, cbuf, sbuf[0..1]), 2 for the transformer output and the last conv's input.  A sequence owns whole 16-row tiles, i.e.
+  // one contiguous block of every buffer, at element offset row * (elements per sequence) inside either parity half.
+  const bool h16 = s->e->codec_bf16, f8 = s->e->codec_fp8;
+  const int e_tr = h16 ? 2 : 4, e_a0 = f8 ? 1 : h16 ? 2 : 4;
   set_int_kernel<<<1, 64, 0, st>>>(s->offset + row, 1, 0);
+  auto zero_block = [&](float *buf, long stride_floats, int par, int esz) -> hipError_t {
+    const size_t per_seq = (size_t)stride_floats / s->B;  // elements
+    return hipMemsetAsync((char *)buf + (size_t)par * stride_floats * 4 + (size_t)row * per_seq * esz, 0, per_seq * esz, st);
+  };
   for (int par = 0; par < 2; ++par) {
     zero_row_fm_kernel<<<cdiv(CF * 16, 256), 256, 0, st>>>(s->zq + par * s->zq_stride, CF, row);
-    // 16-row tiles: a sequence owns whole tiles, i.e. one contiguous block of every FM buffer
-    const size_t tr = (size_t)s->tr_stride / s->B / div, a0 = (size_t)s->a0_stride / s->B / div;
-    HIPCHK(hipMemsetAsync(s->tr_out + par * s->tr_stride + row * tr, 0, tr * 4, st));
-    HIPCHK(hipMemsetAsync(s->a0 + par * s->a0_stride + row * a0, 0, a0 * 4, st));
+    HIPCHK(zero_block(s->tr_out, s->tr_stride, par, e_tr));
+    HIPCHK(zero_block(s->a0, s->a0_stride, par, e_a0));
     for (int i = 0; i < 3; ++i) {
-      const size_t cs = (size_t)s->c_stride[i] / s->B / div, ss = (size_t)s->s_stride[i] / s->B / div;
-      HIPCHK(hipMemsetAsync(s->cbuf[i] + par * s->c_stride[i] + row * cs, 0, cs * 4, st));
-      HIPCHK(hipMemsetAsync(s->sbuf[i] + par * s->s_stride[i] + row * ss, 0, ss * 4, st));
+      HIPCHK(zero_block(s->cbuf[i], s->c_stride[i], par, e_a0));
+      HIPCHK(zero_block(s->sbuf[i], s->s_stride[i], par, (f8 && i == 2) ? 2 : e_a0));
     }
   }
   HIPCHK(hipGetLastError());
@@ -2091,16 +2223,34 @@ static int mimi_enqueue_h(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, co
     a.Y = last ? s->tr_out : s->u; a.YF = CB; a.Ydstride = last ? 2 * s->tr_stride : 0; a.par = last ? s->frame : nullptr;
     launch_gemm_h(st, a, PRE_NONE, T.ff2);
   }
-  // strides of the frame-parity double buffers: the float buffers hold bf16, so a parity step of `stride` floats is
-  // 2 * stride bf16 elements
+  // strides of the frame-parity double buffers: the float buffers hold bf16 (or, for the inputs of the fp8 convolutions,
+  // e4m3 bytes), so a parity step of `stride` floats is 2 * stride bf16 elements / 4 * stride bytes
+  const bool f8 = e->codec_fp8;
+  const float *f8s = e->f8s;
+  // fp8 conv: operand images, scales and output format (sc_in / sc_out index e->f8s; sc_out < 0: bf16 output)
+  auto f8_conv = [&](GemmArgs &g, const Lin &L, int sc_in, int sc_out) {
+    g.W = (const float *)L.wf8;
+    g.wscale = L.wscale8;
+    g.CF = L.C / 32;
+    g.KF = g.CF * L.ntaps;
+    g.swz = 0;
+    g.xs = f8s[sc_in];
+    g.yf8 = sc_out >= 0;
+    g.yinv = sc_out >= 0 ? 1.0f / f8s[sc_out] : 1.0f;
+    const double K = (double)g.KF * 32, N = (double)g.NT * 16, M = (double)g.M;
+    ProfScope ps(st, "gemm_f8@" + std::to_string((long)g.NT * g.MT), N * K + M * g.CF * 32.0 + M * N * (g.yf8 ? 1 : 2) + (g.Yraw ? 2.0 * M * N : 0.0) +
+                         (g.epi == EPI_RES ? 2.0 * M * N : 0.0), 2.0 * M * N * K);
+    launch_gemm_f8(st, g, lds_pad(0));
+  };
   int mult = 8;
   SITE("seanet.conv0");
   a = mk_gemm(e->conv0, s->tr_out, CB, MT16, M16);
   a.Xdstride = 2 * s->tr_stride; a.T = s->rows[0]; a.par = s->frame;
-  a.Y = s->a0; a.Ydstride = 2 * s->a0_stride; a.YF = mult * c.n_filters / 32; a.act = ACT_ELU;
+  a.Y = s->a0; a.Ydstride = (f8 ? 4 : 2) * s->a0_stride; a.YF = mult * c.n_filters / 32; a.act = ACT_ELU;
+  if (f8) { a.yf8 = 1; a.yinv = 1.0f / f8s[0]; }  // bf16 in (the transformer's output), e4m3 out
   launch_gemm_h(st, a, PRE_NONE, e->conv0);
   const float *xin = s->a0;
-  long xds = 2 * s->a0_stride;
+  long xds = (f8 ? 4 : 2) * s->a0_stride;
   for (int i = 0; i < 3; ++i) {
     const int cin = mult * c.n_filters, cout = cin / 2, hid = cout / c.compress;
     const int Tin = s->rows[i], Tout = s->rows[i + 1];
@@ -2108,26 +2258,31 @@ static int mimi_enqueue_h(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, co
     static const char *sn[3][3] = {{"seanet.convtr1", "seanet.res1a", "seanet.res1b"},
                                    {"seanet.convtr2", "seanet.res2a", "seanet.res2b"},
                                    {"seanet.convtr3", "seanet.res3a", "seanet.res3b"}};
+    const int es = f8 ? 4 : 2;  // elements per float of stride for the buffers that follow the codec's operand format
+    const bool s_bf16 = !f8 || i == 2;  // the last block's output feeds the (bf16-input) last conv
     SITE(sn[i][0]);
     a = mk_gemm(e->convtr[i], xin, cin / 32, MTin, B * Tin);
     a.Xdstride = xds; a.T = Tin; a.par = s->frame;
     a.epi = EPI_CONVTR; a.cout = cout; a.stride = c.ratios[i];
-    a.Y = s->cbuf[i]; a.Ydstride = 2 * s->c_stride[i]; a.YF = cout / 32; a.act = ACT_ELU;
+    a.Y = s->cbuf[i]; a.Ydstride = es * s->c_stride[i]; a.YF = cout / 32; a.act = ACT_ELU;
     a.Yraw = s->craw[i]; a.Yrawdstride = 0;
-    launch_gemm_h(st, a, PRE_NONE, e->convtr[i]);
+    if (f8) f8_conv(a, e->convtr[i], i == 0 ? 0 : 3 * i, 1 + 3 * i);
+    else launch_gemm_h(st, a, PRE_NONE, e->convtr[i]);
     SITE(sn[i][1]);
     a = mk_gemm(e->res_a[i], s->cbuf[i], cout / 32, MTout, B * Tout);
-    a.Xdstride = 2 * s->c_stride[i]; a.T = Tout; a.par = s->frame;
+    a.Xdstride = es * s->c_stride[i]; a.T = Tout; a.par = s->frame;
     a.Y = s->rbuf[i]; a.YF = hid / 32; a.act = ACT_ELU;
-    launch_gemm_h(st, a, PRE_NONE, e->res_a[i]);
+    if (f8) f8_conv(a, e->res_a[i], 1 + 3 * i, 2 + 3 * i);
+    else launch_gemm_h(st, a, PRE_NONE, e->res_a[i]);
     SITE(sn[i][2]);
     a = mk_gemm(e->res_b[i], s->rbuf[i], hid / 32, MTout, B * Tout);
     a.T = Tout; a.par = s->frame;
     a.epi = EPI_RES; a.R = s->craw[i]; a.Rdstride = 0; a.RF = cout / 32; a.act = ACT_ELU;
-    a.Y = s->sbuf[i]; a.Ydstride = 2 * s->s_stride[i]; a.YF = cout / 32;
-    launch_gemm_h(st, a, PRE_NONE, e->res_b[i]);
+    a.Y = s->sbuf[i]; a.Ydstride = (s_bf16 ? 2 : 4) * s->s_stride[i]; a.YF = cout / 32;
+    if (f8) f8_conv(a, e->res_b[i], 2 + 3 * i, s_bf16 ? -1 : 3 + 3 * i);
+    else launch_gemm_h(st, a, PRE_NONE, e->res_b[i]);
     xin = s->sbuf[i];
-    xds = 2 * s->s_stride[i];
+    xds = (s_bf16 ? 2 : 4) * s->s_stride[i];
     mult /= 2;
   }
   const int Tl = s->rows[3];
@@ -2740,7 +2895,7 @@ extern "C" int ptts_timer_stop_ms(ptts_engine *e, void *stream, float *ms) {
   return 0;
 }
 extern "C" int64_t ptts_lm_weight_bytes(ptts_engine *e) { return e->lm_bytes; }
-extern "C" int64_t ptts_mimi_weight_bytes(ptts_engine *e) { return e->codec_bf16 ? e->mimi_bytes_h : e->mimi_bytes; }
+extern "C" int64_t ptts_mimi_weight_bytes(ptts_engine *e) { return e->codec_fp8 ? e->mimi_bytes_f8 : e->codec_bf16 ? e->mimi_bytes_h : e->mimi_bytes; }
 
 extern "C" int64_t ptts_debug_read(ptts_engine *e, void *state, int32_t is_mimi, const char *name, float *d_out,
                                    int64_t capacity, int32_t *rows, int32_t *cols, void *stream) {

@@ -18,7 +18,7 @@
 // prologue write FMH outputs too)
 
 // load-time packing (same value(n, c, tap) convention as pack_weight_kernel): dst[nt][tap*CB+cb][lane][j8]
-__global__ void pack_weight_h_kernel(const float *src, __bf16 *dst, int N, int C, int ntaps, int mode, int cout, int stride,
+static __global__ void pack_weight_h_kernel(const float *src, __bf16 *dst, int N, int C, int ntaps, int mode, int cout, int stride,
                                      int KBt, long total, const float *colscale) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -41,7 +41,7 @@ __global__ void pack_weight_h_kernel(const float *src, __bf16 *dst, int N, int C
 }
 // LayerNorm-fold vector s[n] = sum_k W'[n][k] from the ROUNDED packed weights (the fold y = rstd (W'x - mean s) + c
 // cancels exactly only if s matches what the MFMA multiplies with); one wave per output row, ntaps == 1
-__global__ void fold_s_h_kernel(const __bf16 *Wp, float *s_out, int N, int KB) {
+static __global__ void fold_s_h_kernel(const __bf16 *Wp, float *s_out, int N, int KB) {
   const int n = blockIdx.x, lane = threadIdx.x;
   const __bf16 *base = Wp + ((size_t)(n >> 4) * KB * 64 + (n & 15)) * 8;
   float s = 0.f;
@@ -65,7 +65,9 @@ __device__ __forceinline__ void gemm_h_epilogue(const GemmArgs &a, f32x4 acc, in
     case EPI_STORE: {
       const size_t o = fmh_off(m, n0, a.YF);
       if (a.Yraw) *(bf16x4 *)((__bf16 *)a.Yraw + par * a.Yrawdstride + o) = to_bf16x4(acc);
-      *(bf16x4 *)((__bf16 *)a.Y + par * a.Ydstride + o) = to_bf16x4(act4(acc, a.act));
+      // yf8: the consumer is an fp8 convolution (PTTS_CODEC_FP8): same element order, one byte per element
+      if (a.yf8) *(unsigned *)((uint8_t *)a.Y + par * a.Ydstride + o) = to_f8x4(act4(acc, a.act) * a.yinv);
+      else *(bf16x4 *)((__bf16 *)a.Y + par * a.Ydstride + o) = to_bf16x4(act4(acc, a.act));
     } break;
     case EPI_RES: {
       const f32x4 rv = from_bf16x4(*(const bf16x4 *)((const __bf16 *)a.R + par * a.Rdstride + fmh_off(m, n0, a.RF)));
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(64 * WN * WM) void gemm_h_kernel(GemmArgs a) {
 
 // SEANet's last conv (n_filters -> 1 sample) on a bf16 input: thread = one output sample, weights plain fp32
 // [C][ntaps] (the checkpoint tensor), input FMH double-buffered by frame parity
-__global__ __launch_bounds__(256) void pcm_conv_h_kernel(GemmArgs a, const float *wplain, const float *bplain) {
+static __global__ __launch_bounds__(256) void pcm_conv_h_kernel(GemmArgs a, const float *wplain, const float *bplain) {
   const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= a.M) return;
   const int par = a.par ? (*a.par & 1) : 0;

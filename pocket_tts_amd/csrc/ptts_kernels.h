@@ -33,6 +33,15 @@ __device__ __forceinline__ size_t fmh_off(size_t row, int n0, int KB) {
   return (((row >> 4) * KB + (n0 >> 5)) * 64 + (((n0 & 31) >> 3) * 16 + (row & 15))) * 8 + (n0 & 7);
 }
 
+// four floats -> four OCP e4m3 bytes (gfx950 v_cvt_pk_fp8_f32; saturating by an explicit clamp to +-448), one dword
+__device__ __forceinline__ unsigned to_f8x4(f32x4 v) {
+  v.x = fminf(fmaxf(v.x, -448.f), 448.f); v.y = fminf(fmaxf(v.y, -448.f), 448.f);
+  v.z = fminf(fmaxf(v.z, -448.f), 448.f); v.w = fminf(fmaxf(v.w, -448.f), 448.f);
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(v.x, v.y, 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(v.z, v.w, r, true);
+  return (unsigned)r;
+}
+
 // Ablation switches for tests/hip/bench_gemm.hip only (timing builds; results are wrong when set):
 // 1 = no X loads, 2 = no W loads, 4 = no MFMA; gemm_lds_kernel: 8 = no DMA wait, 16 = no stage barrier, 32 = no DMA after the prologue;
 // gemm_kernel: 64 = no PRE_LNMOD statistics pass; 128 = GEMM and attention kernels return at once.
@@ -72,6 +81,10 @@ struct GemmArgs {
   // per lane carries the lane's operands of FOUR consecutive k-fragments; y[n] = wscale[n] * sum_k q[n][k] x[k]
   const uint8_t *Wq;
   const float *wscale;
+  // weight image format: 0 = fp32 (W), 1 = int8 (Wq, above), 2 = bf16 (Wq reinterpreted as __bf16, packed [NT][KF/2][64][8]:
+  // lane (g, n) holds W[n][32 kb + 4 g + 0..3] and W[n][32 kb + 16 + 4 g + 0..3], i.e. the lane's operands of the two fp32
+  // k-fragments 2 kb and 2 kb + 1, so the activation operand is the two fp32 fragments converted in registers, no shuffle)
+  int wfmt;
   int swz;  // XCD-aware workgroup -> tile mapping (tile_of_block)
   int krot;  // Linear layers, K-split tiles: workgroup bx starts its K loop at chunk bx % nchunks, so the column blocks that
              // re-read the same activation rows do not request the same L2 lines at the same time
@@ -138,6 +151,10 @@ struct GemmArgs {
   // the same launch (Y / R / YF / RF / Ydstride then describe ITS output and skip input): packed [NT2][NT][64][4]
   const float *W2, *bias2;
   int act2;
+  // fp8 codec convolutions (ptts_fp8.hip): xs = scale of the e4m3 activation operand (real = stored * xs); yf8 != 0: the
+  // output Y is e4m3 in the FM8 layout, stored as value * yinv (yinv = 1 / scale of that tensor); else Y is bf16 FMH
+  float xs, yinv;
+  int yf8;
   // EPI_PCM
   float *pcm;
   int16_t *pcm_i16;  // optional 16-bit copy: (clamp(x, -1, 1) * 32767) truncated, as data/audio.py:79
@@ -299,9 +316,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 acc, int 
 }
 
 // TN x TM 16x16 tiles per wave; WK waves split K (LDS-reduced), WN x WM waves tile N x M.
-template <int TN, int TM, int WK, int WN, int WM, int PRE, bool Q8 = false>
+template <int TN, int TM, int WK, int WN, int WM, int PRE, int WF = 0>
 __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
   if constexpr (PTTS_ABLATE & 128) return;  // ablation 128 (timing only): empty kernels = launch + boundary cost
+  constexpr bool Q8 = WF == 1;   // int8 weights, fp32 activations, fp32 MFMA
+  constexpr bool B16 = WF == 2;  // bf16 weights, activations rounded to bf16 in registers, v_mfma_f32_16x16x32_bf16
   constexpr int NW = WK * WN * WM;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -336,7 +355,7 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
   for (int i = 0; i < TN; ++i) {
     int nt = nt0 + i < a.NT ? nt0 + i : a.NT - 1;
     wb[i] = a.W + (size_t)nt * a.KF * 256 + lane * 4;
-    wqb[i] = Q8 ? a.Wq + (size_t)nt * a.KF * 256 + lane * 16 : nullptr;
+    wqb[i] = Q8 ? a.Wq + (size_t)nt * a.KF * 256 + lane * 16 : B16 ? a.Wq + (size_t)nt * a.KF * 512 + lane * 16 : nullptr;
   }
   int mtc[TM], tin[TM], bT[TM];
 #pragma unroll
@@ -469,7 +488,7 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
 #endif
   constexpr int KDIV = (TN * TM == 1) ? PTTS_KSPLIT_DIV1 : PTTS_KSPLIT_DIV;
   constexpr int U0 = (WK > 1) ? (U00 / KDIV >= 1 ? U00 / KDIV : 1) : U00;
-  constexpr int U = (Q8 && U0 < 4) ? 4 : U0;  // int8 weights arrive four k-fragments per load
+  constexpr int U = (Q8 && U0 < 4) ? 4 : (B16 && U0 < 2) ? 2 : U0;  // int8 / bf16 weights arrive four / two k-fragments per load
   auto load_chunk = [&](auto uc, int kf, f32x4 (*w)[TN], f32x4 (*x)[TM]) {
     constexpr int UU = decltype(uc)::value;
     if (a.ntaps == 1) cf = kf;  // a Linear's fragments are addressed by k alone (chunks may come in rotated order)
@@ -484,6 +503,12 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
           if (u % 4 == 0) {
             const i32x4 raw = __builtin_nontemporal_load((const i32x4 *)(wqb[i] + (size_t)(kf + u) * 256));
             w[u / 4][i] = __builtin_bit_cast(f32x4, raw);
+          }
+        } else if constexpr (B16) {
+          // eight bf16 of fragments kf+u, kf+u+1 (kf + u even), parked in slot u/2
+          if (u % 2 == 0) {
+            const i32x4 raw = __builtin_nontemporal_load((const i32x4 *)(wqb[i] + (size_t)((kf + u) >> 1) * 1024));
+            w[u / 2][i] = __builtin_bit_cast(f32x4, raw);
           }
         } else if constexpr (WK > 1) w[u][i] = __builtin_nontemporal_load((const f32x4 *)(wb[i] + (size_t)(kf + u) * 256));
         else w[u][i] = *(const f32x4 *)(wb[i] + (size_t)(kf + u) * 256);
@@ -536,6 +561,21 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
 #pragma unroll
           for (int j = 0; j < TM; ++j) x[u][j] *= g4;
         }
+      }
+      if constexpr (B16) {
+        // one 16x16x32 MFMA per (tile pair, two k-fragments): issued at the odd fragment, when both halves of the
+        // activation operand have gone through the operand pre-processing above
+        if (u % 2 == 1) {
+#pragma unroll
+          for (int j = 0; j < TM; ++j) {
+            const bf16x4 lo = to_bf16x4(x[u - 1][j]), hi = to_bf16x4(x[u][j]);
+            const bf16x8 xb = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+              acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[u / 2][i]), xb, acc[i][j][0], 0, 0, 0);
+          }
+        }
+        continue;
       }
       f32x4 wv[TN];
 #pragma unroll
@@ -596,6 +636,14 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
       f32x4 w4[4][TN], x4[4][TM];
       load_chunk(c4, kf, w4, x4);
       compute_chunk(c4, kf, w4, x4);
+    }
+  }
+  if constexpr (B16) {
+    const std::integral_constant<int, 2> c2{};  // host guarantees (k1 - k0) % 2 == 0
+    for (; kf < k1; kf += 2) {
+      f32x4 w2[2][TN], x2[2][TM];
+      load_chunk(c2, kf, w2, x2);
+      compute_chunk(c2, kf, w2, x2);
     }
   }
   for (; kf < k1; ++kf) {
@@ -698,7 +746,7 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
 // dots its quarter of the channels for every tap and the four quarters meet by two xor-shuffles.  Memory bound:
 // every input row is read once from HBM, the other taps re-read its lines through L1 (plain loads on purpose).  Same GemmArgs (taps, halo rule, frame-parity double buffer, packed weights with NT = 1).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pcm_conv_kernel(GemmArgs a) {
+static __global__ __launch_bounds__(256) void pcm_conv_kernel(GemmArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int mt = blockIdx.x * 4 + wave;
   if (mt >= a.MT) return;
@@ -1008,7 +1056,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
 //         tap 1 (current input row) uses kernel index j, tap 0 (previous row) uses j + s.
 // dst[nt][tap*CF + cf][lane][j4] = W[n = 16nt + (lane&15)][c = 16cf + 4(lane>>4) + j4][tap]
 // ---------------------------------------------------------------------------------------------
-__global__ void pack_weight_kernel(const float *src, float *dst, int N, int C, int ntaps, int mode, int cout,
+static __global__ void pack_weight_kernel(const float *src, float *dst, int N, int C, int ntaps, int mode, int cout,
                                    int stride, int nt_off, int KF, long total, const float *colscale, int Creal) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -1037,7 +1085,7 @@ __global__ void pack_weight_kernel(const float *src, float *dst, int N, int C, i
 
 // LayerNorm folding constants of one Linear [N][K]: s[n] = sum_k W[n][k] g[k], c[n] = sum_k W[n][k] b[k] + bias[n].
 // One wave per output row; load time only.
-__global__ void fold_ln_kernel(const float *W, const float *g, const float *b, const float *bias, float *s_out,
+static __global__ void fold_ln_kernel(const float *W, const float *g, const float *b, const float *bias, float *s_out,
                                float *c_out, int N, int K, int n_off) {
   const int n = blockIdx.x, lane = threadIdx.x;
   float s = 0.f, c = 0.f;
@@ -1061,7 +1109,7 @@ __global__ void fold_ln_kernel(const float *W, const float *g, const float *b, c
 // so the result equals LayerNorm followed by a Linear whose weight is Wdq, which is what the oracle computes.
 // (The reference quantises the same Linear layers with torch.ao / torchao dynamic int8, quantization.py:60-128;
 // this build keeps activations in fp32: weight-only, per channel.)
-__global__ __launch_bounds__(256) void quantize_packed_kernel(const float *src, uint8_t *dst, float *wscale, int KF,
+static __global__ __launch_bounds__(256) void quantize_packed_kernel(const float *src, uint8_t *dst, float *wscale, int KF,
                                                               const float *gam, const float *bet, const float *bias,
                                                               int N, float *ln_s, float *ln_c) {
   __shared__ int smax[16];
@@ -1110,7 +1158,7 @@ __global__ __launch_bounds__(256) void quantize_packed_kernel(const float *src, 
   }
 }
 
-__global__ void pack_bias_kernel(const float *src, float *dst, int N, int mode, int cout, int n_off, int Npad) {
+static __global__ void pack_bias_kernel(const float *src, float *dst, int N, int mode, int cout, int n_off, int Npad) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Npad) return;
   float v = 0.f;
@@ -1121,7 +1169,7 @@ __global__ void pack_bias_kernel(const float *src, float *dst, int N, int mode, 
 // ---------------------------------------------------------------------------------------------
 // Layout conversion: row-major [M][K] <-> FM.  One thread per float4.
 // ---------------------------------------------------------------------------------------------
-__global__ void to_fm_kernel(const float *src, float *dst, int M, int K, int MT) {
+static __global__ void to_fm_kernel(const float *src, float *dst, int M, int K, int MT) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   int KF = K / 16;
   long total = (long)MT * KF * 64;
@@ -1137,7 +1185,7 @@ __global__ void to_fm_kernel(const float *src, float *dst, int M, int K, int MT)
   *(f32x4 *)(dst + i * 4) = v;
 }
 
-__global__ void from_fm_kernel(const float *src, float *dst, int M, int K, int F, int f_off) {
+static __global__ void from_fm_kernel(const float *src, float *dst, int M, int K, int F, int f_off) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   int K4 = K / 4;
   if (i >= (long)M * K4) return;
@@ -1183,7 +1231,7 @@ __device__ __forceinline__ void rope_table_entry(const RopeArgs &r, int i) {
 
 // Step prologue of the FlowLM: BOS substitution + noise + FM conversion of the input latent (blocks < nb_prep) and the
 // step's RoPE table (the remaining blocks): one launch instead of two.
-__global__ void prep_lm_kernel(const float *lat_in, const float *bos, const float *noise, float *x_fm, float *lat,
+static __global__ void prep_lm_kernel(const float *lat_in, const float *bos, const float *noise, float *x_fm, float *lat,
                                float *lat_fm, int B, int ldim, int MT, float rng_std, unsigned long long rng_seed,
                                const int *rng_ctr, int nb_prep, RopeArgs rope) {
   if ((int)blockIdx.x >= nb_prep) {
@@ -1228,7 +1276,7 @@ __global__ void prep_lm_kernel(const float *lat_in, const float *bos, const floa
 //     out[b, t, c] = zq[b, c] w[c, t] + zq_prev[b, c] w[c, s + t]
 // zq is double-buffered by frame parity (FM layout, one row per sequence), so `partial` is never materialised.
 // The three tiny launches this replaces cost more in launch latency than in work.
-__global__ void mimi_prologue_kernel(const float *lat, const float *std, const float *mean, const float *wq,
+static __global__ void mimi_prologue_kernel(const float *lat, const float *std, const float *mean, const float *wq,
                                      const float *wup, float *zq, long zdstride, const int *par_p, float *out, int B,
                                      int ldim, int C, int s, int nb_main, RopeArgs rope, int h16) {
   if ((int)blockIdx.x >= nb_main) {
@@ -1268,12 +1316,12 @@ __global__ void mimi_prologue_kernel(const float *lat, const float *std, const f
   else *(f32x4 *)(out + (((size_t)(m >> 4) * CF + (c >> 4)) * 64 + 16 * ((c & 15) >> 2) + (m & 15)) * 4) = o;
 }
 
-__global__ void rope_table_kernel(const int *offset, const float *freq, float *tab, int M, int Tq) {
+static __global__ void rope_table_kernel(const int *offset, const float *freq, float *tab, int M, int Tq) {
   rope_table_entry(RopeArgs{offset, freq, tab, M, Tq}, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // mono audio [T] -> FM rows of 16 channels (channel 0 = sample, the rest zero) for the encoder's first conv
-__global__ void audio_to_fm_kernel(const float *audio, float *x_fm, int n_valid, int n_rows) {
+static __global__ void audio_to_fm_kernel(const float *audio, float *x_fm, int n_valid, int n_rows) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;  // one float4 slot per (row tile, lane)
   if (i >= (n_rows / 16) * 64) return;
   int lane = i & 63, mt = i >> 6;
@@ -1283,37 +1331,37 @@ __global__ void audio_to_fm_kernel(const float *audio, float *x_fm, int n_valid,
   *(f32x4 *)(x_fm + (size_t)i * 4) = v;
 }
 
-__global__ void add_int_kernel(int *p, int n, int inc) {
+static __global__ void add_int_kernel(int *p, int n, int inc) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] += inc;
 }
 // end-of-step bookkeeping in one launch: offsets of all rows += inc (increment_steps, reference
 // stateful_module.py:19-26) and one scalar counter (noise counter / frame parity) += 1
 // `active` (optional): parked rows of a continuously batched state keep their offset
-__global__ void step_tail_kernel(int *offset, int n, int inc, int *counter, const int *active) {
+static __global__ void step_tail_kernel(int *offset, int n, int inc, int *counter, const int *active) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && (!active || active[i])) offset[i] += inc;
   if (i == 0 && counter) *counter += 1;
 }
 // zero row `row` of an FM buffer with F k-fragments per row tile (a joining utterance's codec carries)
-__global__ void zero_row_fm_kernel(float *buf, int F, int row) {
+static __global__ void zero_row_fm_kernel(float *buf, int F, int row) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;  // (kf, group, j4)
   if (i >= F * 16) return;
   const int kf = i >> 4, g = (i >> 2) & 3, j4 = i & 3;
   buf[(((size_t)(row >> 4) * F + kf) * 64 + 16 * g + (row & 15)) * 4 + j4] = 0.f;
 }
-__global__ void set_int_kernel(int *p, int n, int v) {
+static __global__ void set_int_kernel(int *p, int n, int v) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
-__global__ void fill_kernel(float *p, long n, float v) {
+static __global__ void fill_kernel(float *p, long n, float v) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
 
 // The flow MLP's variance-based "RMSNorm" on one row + average of the two time embeddings
 // (reference mlp.py:20-25,70,204-206).  Load-time constant folding, one wave.
-__global__ void tcomb_kernel(const float *h0_fm, const float *h1_fm, const float *alpha0, const float *alpha1,
+static __global__ void tcomb_kernel(const float *h0_fm, const float *h1_fm, const float *alpha0, const float *alpha1,
                              float *out, int fd) {
   // row 0 of an FM tensor with F = fd/16: element k at ((k/16)*64 + 16*((k%16)/4))*4 + k%4
   const int lane = threadIdx.x;
@@ -1334,7 +1382,7 @@ __global__ void tcomb_kernel(const float *h0_fm, const float *h1_fm, const float
 }
 
 // cat(cos(t f), sin(t f)) for one scalar t -> FM row 0 (reference mlp.py:79-81)
-__global__ void timestep_embed_kernel(const float *freqs, float t, float *e_fm, int half) {
+static __global__ void timestep_embed_kernel(const float *freqs, float t, float *e_fm, int half) {
   int k = threadIdx.x + blockIdx.x * blockDim.x;
   if (k >= 2 * half) return;
   float arg = t * freqs[k % half];
@@ -1845,7 +1893,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode2_kernel(AttnArgs a) {
 }
 
 // merges the key splits: thread (query, 4-wide d group)
-__global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs a) {
+static __global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs a) {
   const int bh = blockIdx.x, qb = blockIdx.y;
   const int b = bh / a.H, h = bh - b * a.H;
   const int qi = threadIdx.x >> 4, c = threadIdx.x & 15;
@@ -1872,7 +1920,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs a) {
 // KV cache import / export between the reference layout f32[2, B, T, H, 64] (transformer.py:32-36)
 // and the internal K[b][h][slot][64], V[b][h][slot][64].
 // ---------------------------------------------------------------------------------------------
-__global__ void kv_import_kernel(const float *src, float *Kc, float *Vc, int B, int srcB, int T, int H, int cap) {
+static __global__ void kv_import_kernel(const float *src, float *Kc, float *Vc, int B, int srcB, int T, int H, int cap) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over [2][B][T][H][16 float4]
   long total = 2L * B * T * H * 16;
   if (i >= total) return;
@@ -1888,7 +1936,7 @@ __global__ void kv_import_kernel(const float *src, float *Kc, float *Vc, int B, 
   *(f32x4 *)(dst + (((size_t)b * H + h) * cap + t) * 64 + d4 * 4) = v;
 }
 
-__global__ void kv_export_kernel(float *dst, const float *Kc, const float *Vc, int B, int T, int H, int cap) {
+static __global__ void kv_export_kernel(float *dst, const float *Kc, const float *Vc, int B, int T, int H, int cap) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = 2L * B * T * H * 16;
   if (i >= total) return;
@@ -1905,7 +1953,7 @@ __global__ void kv_export_kernel(float *dst, const float *Kc, const float *Vc, i
 
 // dst rows <- src rows (src batch 1 broadcasts), whole [L][2][B][H][cap][64] block, equal cap
 // one batch-1 state -> row `row` of a batch state: [planes][1][H][src_cap][64] -> [planes][B][H][dst_cap][64], T positions
-__global__ void kv_copy_row_kernel(float *dst, const float *src, int planes, int H, int T, int src_cap, int dst_cap,
+static __global__ void kv_copy_row_kernel(float *dst, const float *src, int planes, int H, int T, int src_cap, int dst_cap,
                                    int B, int row, int srcB = 1, int src_row = 0) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (plane, head, t, 16 float4)
   if (i >= (long)planes * H * T * 16) return;
@@ -1918,7 +1966,7 @@ __global__ void kv_copy_row_kernel(float *dst, const float *src, int planes, int
   *(f32x4 *)(dst + ((((size_t)pl * B + row) * H + h) * dst_cap + t) * 64 + v * 4) = x;
 }
 
-__global__ void kv_copy_kernel(float *dst, const float *src, long per_row, int B, int srcB, int planes) {
+static __global__ void kv_copy_kernel(float *dst, const float *src, long per_row, int B, int srcB, int planes) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // float4 units over [planes][B][per_row/4]
   long pr4 = per_row / 4;
   long total = (long)planes * B * pr4;

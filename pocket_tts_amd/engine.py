@@ -154,14 +154,17 @@ class MimiState:
 class Engine:
     """Weights of one model on one GPU + entry points of the hot path."""
 
-    QUANT_GROUPS = {"attention": 1, "ffn": 2, "codec_bf16": 4}  # PTTS_QUANT_* / PTTS_CODEC_BF16 (include/ptts.h)
+    # PTTS_QUANT_* / PTTS_CODEC_BF16 / PTTS_CODEC_FP8 / PTTS_LM_BF16 (include/ptts.h)
+    QUANT_GROUPS = {"attention": 1, "ffn": 2, "codec_bf16": 4, "codec_fp8": 8, "lm_bf16": 16}
 
     def __init__(self, cfg: Config, weights: dict, device: str | torch.device = "cuda:0",
                  quantize_groups: set | frozenset | None = None, _packed: str | None = None):
         """`quantize_groups`: subset of {"attention", "ffn"} (the keys of the reference's
         quantization.apply_dynamic_int8): those Linear layers of the FlowLM transformer get int8 weights; plus
-        "codec_bf16": the Mimi decoder runs with bf16 weights / activations and fp32 accumulation (no reference
-        counterpart; BASELINE.json config #5)."""
+        "codec_bf16": the Mimi decoder runs with bf16 weights / activations and fp32 accumulation; "codec_fp8": its SEANet
+        convolutions run on the fp8 MFMA (e4m3 weights + activations, the transformer as under codec_bf16); "lm_bf16": bf16
+        weights and bf16-rounded activation operands for the FlowLM transformer's Linear layers (no reference counterpart
+        for any of the three; BASELINE.json config #5 / SURVEY 8(f).4)."""
         self.lib = _lib.load()
         self.handle = None
         self._states = weakref.WeakSet()

@@ -114,10 +114,12 @@ class TTSModel:
     def load_model(cls, language: str | None = None, config: str | Path | None = None,
                    temp: float | int = DEFAULT_TEMPERATURE, lsd_decode_steps: int = DEFAULT_LSD_DECODE_STEPS,
                    noise_clamp: float | int | None = DEFAULT_NOISE_CLAMP, eos_threshold: float = DEFAULT_EOS_THRESHOLD,
-                   quantize: bool = False, device: str = "cuda:0", tokenizer=None, codec_bf16: bool = False):
-        """Same arguments and errors as the reference (tts_model.py:232-315) plus `device`, `tokenizer` and
-        `codec_bf16` (bf16 Mimi decoder with fp32 accumulation: this build's reduced-precision codec, no reference
-        counterpart)."""
+                   quantize: bool = False, device: str = "cuda:0", tokenizer=None, codec_bf16: bool = False,
+                   codec_fp8: bool = False, lm_bf16: bool = False):
+        """Same arguments and errors as the reference (tts_model.py:232-315) plus `device`, `tokenizer` and this build's
+        reduced-precision formats (no reference counterpart): `codec_bf16` (bf16 Mimi decoder, fp32 accumulation),
+        `codec_fp8` (SEANet convolutions on the fp8 MFMA, transformer bf16), `lm_bf16` (bf16 weights / operands for the
+        FlowLM Linear layers; exclusive with `quantize`)."""
         if config is not None and language is not None:
             raise ValueError("Cannot specify both config and language, please choose one or the other.")
         if config is None and language is None:
@@ -139,7 +141,8 @@ class TTSModel:
             tokenizer = SentencePieceTokenizer(cfg.flow_lm.lookup_table.n_bins, tp)
         # quantize=True: int8 weights for the reference's RECOMMENDED_CONFIG groups (quantization.py:21,
         # tts_model.py:312-315); weight-only and per output channel here (see include/ptts.h)
-        groups = ({"attention", "ffn"} if quantize else set()) | ({"codec_bf16"} if codec_bf16 else set())
+        groups = (({"attention", "ffn"} if quantize else set()) | ({"codec_bf16"} if codec_bf16 else set())
+                  | ({"codec_fp8"} if codec_fp8 else set()) | ({"lm_bf16"} if lm_bf16 else set()))
         engine = Engine(cfg, weights, device, quantize_groups=groups or None)
         return cls(engine, cfg, tokenizer, temp, lsd_decode_steps, noise_clamp, eos_threshold, origin=config)
 
