@@ -58,6 +58,7 @@ PRESETS = {
     "fp8codec": dict(codec_fp8=True),
     "config5fp8": dict(quantize=True, codec_fp8=True),   # BASELINE.json configs[4] as worded: int8 LM weights + fp8 codec convs
     "lmbf16": dict(lm_bf16=True),
+    "split": dict(codec_split=True),   # error-compensated bf16x3 codec GEMMs: beside the headline
 }
 
 
@@ -82,6 +83,8 @@ def parse(argv=None):
                     help="BASELINE config #5, second half: bf16 Mimi decoder, fp32 accumulate (not the headline)")
     ap.add_argument("--codec-fp8", action="store_true", default=None,
                     help="BASELINE config #5: SEANet convolutions on the fp8 MFMA, transformer bf16 (not the headline)")
+    ap.add_argument("--codec-split", action="store_true", default=None,
+                    help="codec GEMMs as hi*hi + hi*lo + lo*hi of bf16 halves, fp32 accumulate (experiment, not the headline)")
     ap.add_argument("--lm-bf16", action="store_true", default=None,
                     help="bf16 weights + operands for the FlowLM Linear layers, fp32 accumulate (not the headline)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the cpu_baseline leg")
@@ -102,6 +105,7 @@ def parse(argv=None):
     args.codec_bf16 = bool(args.codec_bf16)
     args.codec_fp8 = bool(args.codec_fp8)
     args.lm_bf16 = bool(args.lm_bf16)
+    args.codec_split = bool(args.codec_split)
     return args
 
 
@@ -521,7 +525,8 @@ def main():
     cfg = named_config(args.config)
     W = generate_state_dict(cfg, 0)
     groups = (({"attention", "ffn"} if args.quantize else set()) | ({"codec_bf16"} if args.codec_bf16 else set())
-              | ({"codec_fp8"} if args.codec_fp8 else set()) | ({"lm_bf16"} if args.lm_bf16 else set()))
+              | ({"codec_fp8"} if args.codec_fp8 else set()) | ({"lm_bf16"} if args.lm_bf16 else set())
+              | ({"codec_split"} if args.codec_split else set()))
     eng = Engine(cfg, W, dev, quantize_groups=groups or None)
     job = Job(eng, args.batch, args, seed=rank)
 
@@ -606,6 +611,7 @@ def main():
             "vs_baseline": None,
             "dtype": " + ".join(([("int8 weights (FlowLM attention+ffn), f32 activations/accumulate")] if args.quantize else [])
                                 + (["bf16 FlowLM Linear weights + operands, f32 accumulate"] if args.lm_bf16 else [])
+                                + (["f32 FlowLM + codec GEMMs on split bf16 (hi*hi + hi*lo + lo*hi, f32 accumulate, f32 buffers)"] if args.codec_split else [])
                                 + (["bf16 codec (weights+activations), f32 accumulate"] if args.codec_bf16 else [])
                                 + (["fp8 e4m3 SEANet convs + bf16 Mimi transformer, f32 accumulate"] if args.codec_fp8 else [])) or "f32",
             "data": "synthetic (seeded weights, voice KV, token ids; fixed-length utterances, EOS stop disabled)",

@@ -88,6 +88,11 @@ int ptts_create(const ptts_config *cfg, const ptts_tensor *tensors, int32_t n_te
  * fp32 (the bf16 image is widened in registers and fed to the fp32 MFMA), half the weight bytes of a decode step.
  * Exclusive with the int8 groups.  Quality: tests/test_gpu_quant.py. */
 #define PTTS_LM_BF16 16
+/* ERROR-COMPENSATED bf16 for the codec's GEMMs (an experiment reported beside the fp32 headline): every Linear / conv of the
+ * Mimi decoder as hi*hi + hi*lo + lo*hi of bf16 halves (hi = bf16(v), lo = bf16(v - hi)) on the bf16 MFMA with fp32
+ * accumulation; activations, buffers, attention and epilogues stay fp32.  ~2^-16 relative error per product; passes the fp32
+ * codec's parity tests at their tolerance (tests/test_gpu_split.py).  Exclusive with the bf16 / fp8 codec. */
+#define PTTS_CODEC_SPLIT 32
 int ptts_create_ex(const ptts_config *cfg, const ptts_tensor *tensors, int32_t n_tensors, int32_t device,
                    int32_t quant_flags, ptts_engine **out);
 /* Packed-engine files ("offline packer"): ptts_engine_save writes everything ptts_create[_ex] built on

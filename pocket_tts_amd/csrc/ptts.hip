@@ -73,6 +73,8 @@ struct Lin {  // one packed weight matrix
   float *wscale = nullptr, *ln_g = nullptr;
   // bf16 weight variant of a FlowLM Linear (PTTS_LM_BF16): replaces w; packed [NT][KF/2][64][8] (GemmArgs::wfmt == 2)
   void *wb16 = nullptr;
+  // split-bf16 twin of a codec matrix (PTTS_CODEC_SPLIT): hi = bf16(w), lo = bf16(w - hi) images beside the fp32 one
+  void *wsh = nullptr, *wsl = nullptr;
   // bf16 twin for the reduced-precision codec path (PTTS_CODEC_BF16): packed [NT][ntaps * C/32][64][8], ln_s from the rounded image
   __bf16 *wh = nullptr;
   float *ln_s_h = nullptr;
@@ -121,6 +123,7 @@ struct ptts_engine {
   // fp8 SEANet convolutions: static activation scales (device copy lives in an engine allocation, so packed-engine files
   // carry it; f8s is its host mirror).  Index: 0 = conv0 output, 1 + 3 i = convtr_i output (ELU'd), 2 + 3 i = hidden
   // activation of residual block i, 3 + 3 i = output of block i (i < 2: the next transposed conv's input)
+  bool codec_split = false;  // PTTS_CODEC_SPLIT: the fp32 codec's GEMM launches use the split-bf16 images
   bool codec_fp8 = false;
   float *d_f8s = nullptr;
   float f8s[16] = {};
@@ -532,7 +535,10 @@ static bool q8_cfg(int cfg) { return cfg == 0 || cfg == 1 || cfg == 2 || cfg == 
 
 static bool cfg_valid(int cfg, const GemmArgs &a, int pre) {
   const int *s = kCfgShape[cfg];
-  if (a.wfmt) {  // whole groups of four (int8) / two (bf16) k-fragments per wave
+  if (a.wfmt == 3) {  // split bf16: every register-staged configuration, whole pairs of k-fragments per wave
+    if (!split_cfg(cfg) || (pre != PRE_NONE && pre != PRE_LNFOLD)) return false;
+    if (a.KF % (2 * s[2])) return false;
+  } else if (a.wfmt) {  // whole groups of four (int8) / two (bf16) k-fragments per wave
     if (!q8_cfg(cfg) || (pre != PRE_NONE && pre != PRE_LNFOLD)) return false;
     // bf16 weights: the 8-wave single-tile configuration is excluded - its bf16 instantiation produced NaNs on the GPU
     // (gpurun_out/r3 debug run, every shape) while the 4-wave K-split and the 2-D tilings are exact; not understood yet
@@ -566,6 +572,11 @@ static void launch_by_cfg(hipStream_t st, const GemmArgs &a_in, int pre, int cfg
   a.swz = swz_for(cfg, a);
   if (a.wfmt == 2) {
     launch_gemm_b16(st, a, pre, cfg, 0);
+    return;
+  }
+  if (a.wfmt == 3) {
+    const int *sh = kCfgShape[cfg];
+    launch_gemm_split(st, a, pre, cfg, lds_pad(sh[2] > 1 ? sh[2] * sh[3] * sh[4] * sh[0] * sh[1] * 1024 : 0));
     return;
   }
   if (a.wfmt == 1) {
@@ -616,6 +627,7 @@ struct Tuner {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   std::string log;
 };
+static thread_local bool g_use_split = false;  // set around the codec's enqueue by engines built with PTTS_CODEC_SPLIT
 static thread_local Tuner *g_tuner = nullptr;
 static thread_local const float *g_zeros = nullptr;  // both set by the entry points from the engine
 static thread_local int g_krot = 1;
@@ -714,7 +726,11 @@ static void launch_gemm(hipStream_t st, const GemmArgs &a_in, int pre) {
       if (f[0] == a.NT && f[1] == a.MT && f[2] >= 0 && f[2] < kNumCfg && cfg_valid(f[2], a, pre)) cfg = f[2];
   }
   if (cfg < 0 || !cfg_valid(cfg, a, pre)) cfg = pick_cfg(a);
-  if (a.wfmt && !cfg_valid(cfg, a, pre)) cfg = (a.wfmt == 2 && !cfg_valid(3, a, pre) && cfg_valid(11, a, pre)) ? 11 : 3;
+  if (a.wfmt == 3 && !cfg_valid(cfg, a, pre)) {  // the heuristic may name an LDS-staged tile: nearest register-staged one
+    cfg = a.MT >= 8 ? 3 : 13;
+    for (int c : {3, 13, 4, 6, 11}) if (cfg_valid(c, a, pre)) { cfg = c; break; }
+  }
+  if (a.wfmt && a.wfmt != 3 && !cfg_valid(cfg, a, pre)) cfg = (a.wfmt == 2 && !cfg_valid(3, a, pre) && cfg_valid(11, a, pre)) ? 11 : 3;
   if (a.wfmt == 1) bytes -= 3.0 * N * K;  // one byte per weight
   if (a.wfmt == 2) bytes -= 2.0 * N * K;  // two
   // label = configuration + operand variant + "@<work-items>" (what rocprofv3 reports as Grid_Size), so that the
@@ -724,14 +740,14 @@ static void launch_gemm(hipStream_t st, const GemmArgs &a_in, int pre) {
                               : (long)cdiv(a.NT, sh[0] * sh[3]) * cdiv(a.MT, sh[1] * sh[4]);
   const long threads = wgs * (sh[2] == 0 ? 256 : 64 * sh[2] * sh[3] * sh[4]);
   ProfScope ps(st, std::string(kCfgName[cfg]) + (pre == PRE_NONE ? "" : pre == PRE_LNFOLD ? "+ln" : pre == PRE_LNMOD ? "+lnmod" : "+addsilu") +
- (a.wfmt == 1 ? "+q8" : a.wfmt == 2 ? "+b16" : "") + "@" + std::to_string(threads), bytes, 2.0 * M * N * K);
+  (a.wfmt == 1 ? "+q8" : a.wfmt == 2 ? "+b16" : a.wfmt == 3 ? "+split" : "") + "@" + std::to_string(threads), bytes, 2.0 * M * N * K);
   launch_by_cfg(st, a, pre, cfg);
 }
 
 // k3 conv + ELU + 1x1 conv + skip of a SEANet residual block in one launch (a = the k3 conv's arguments with Y / R
 // already describing the block's output and skip input)
 static bool resblock_fusable(const Lin &A, const Lin &Bl, int MT) {
-  return !A.wq && !Bl.wq && A.bias && Bl.bias && Bl.ntaps == 1 && Bl.KF == A.NT && A.KF % 2 == 0 && MT >= 4 &&
+  return !(g_use_split && A.wsh) && !A.wq && !Bl.wq && A.bias && Bl.bias && Bl.ntaps == 1 && Bl.KF == A.NT && A.KF % 2 == 0 && MT >= 4 &&
          ((A.NT == 2 && Bl.NT == 4) || (A.NT == 4 && Bl.NT == 8));
 }
 static void launch_resblock(hipStream_t st, GemmArgs a, const Lin &Bl) {
@@ -758,6 +774,11 @@ static GemmArgs mk_gemm(const Lin &L, const float *X, int XF, int MT, int M) {
   a.W = L.w;
   a.Wq = L.wq ? L.wq : (const uint8_t *)L.wb16;
   a.wfmt = L.wq ? 1 : L.wb16 ? 2 : 0;
+  if (g_use_split && L.wsh) {  // codec launches of a PTTS_CODEC_SPLIT engine: hi image in Wq, lo image in W
+    a.Wq = (const uint8_t *)L.wsh;
+    a.W = (const float *)L.wsl;
+    a.wfmt = 3;
+  }
   a.wscale = L.wscale;
   a.ln_g = L.ln_g;
   a.bias = L.bias;
@@ -947,8 +968,9 @@ extern "C" int ptts_create(const ptts_config *cfg, const ptts_tensor *tensors, i
 extern "C" int ptts_create_ex(const ptts_config *cfg, const ptts_tensor *tensors, int32_t n, int32_t device,
                               int32_t quant_flags, ptts_engine **out) {
   if (!cfg || !tensors || !out) return fail(-1, "null argument");
-  if (quant_flags & ~(PTTS_QUANT_ATTENTION | PTTS_QUANT_FFN | PTTS_CODEC_BF16 | PTTS_CODEC_FP8 | PTTS_LM_BF16)) return fail(-1, "unknown quantisation group");
+  if (quant_flags & ~(PTTS_QUANT_ATTENTION | PTTS_QUANT_FFN | PTTS_CODEC_BF16 | PTTS_CODEC_FP8 | PTTS_LM_BF16 | PTTS_CODEC_SPLIT)) return fail(-1, "unknown quantisation group");
   if ((quant_flags & PTTS_CODEC_BF16) && (quant_flags & PTTS_CODEC_FP8)) return fail(-1, "PTTS_CODEC_BF16 and PTTS_CODEC_FP8 are exclusive");
+  if ((quant_flags & PTTS_CODEC_SPLIT) && (quant_flags & (PTTS_CODEC_BF16 | PTTS_CODEC_FP8))) return fail(-1, "PTTS_CODEC_SPLIT and the bf16 / fp8 codec are exclusive");
   if ((quant_flags & PTTS_LM_BF16) && (quant_flags & (PTTS_QUANT_ATTENTION | PTTS_QUANT_FFN))) return fail(-1, "PTTS_LM_BF16 and the int8 groups are exclusive");
   CHK(seanet_check(*cfg));
   HIPCHK(hipSetDevice(device));
@@ -1094,6 +1116,19 @@ static int build_engine(ptts_engine *e, const ptts_tensor *tensors, int32_t n) {
     e->mimi_bytes_h += (int64_t)C * c.ldim * 4;
   }
   if (e->quant_flags & PTTS_CODEC_FP8) CHK(build_fp8_codec(e));
+  if (e->quant_flags & PTTS_CODEC_SPLIT) {
+    std::vector<Lin *> ls = {&e->conv0};
+    for (auto &T : e->mm) { ls.push_back(&T.qkv); ls.push_back(&T.out); ls.push_back(&T.ff1); ls.push_back(&T.ff2); }
+    for (int i = 0; i < 3; ++i) { ls.push_back(&e->convtr[i]); ls.push_back(&e->res_a[i]); ls.push_back(&e->res_b[i]); }
+    for (Lin *L : ls) {
+      if (L->KF % 2) return fail(-4, "split-bf16 codec: every codec matrix needs an even number of 16-wide k-fragments");
+      CHK(dalloc(e, &L->wsh, (size_t)L->NT * L->KF * 512));
+      CHK(dalloc(e, &L->wsl, (size_t)L->NT * L->KF * 512));
+      pack_weight_split(e->stream, L->w, L->wsh, L->wsl, L->NT, L->KF);
+    }
+    HIPCHK(hipGetLastError());
+    e->codec_split = true;
+  }
   if (e->blob_dummy ? e->blob_has_encoder != 0
                     : (e->tmap.count("mimi.encoder.model.0.conv.weight") && e->tmap.count("flow_lm.speaker_proj_weight"))) {
     // reference mimi.py:96-119, seanet.py:63-104, resample.py:7-29, tts_model.py:379-388
@@ -1269,7 +1304,7 @@ extern "C" int ptts_create_from_file(const char *path, int32_t device, ptts_engi
   }
   std::vector<int64_t> sizes((size_t)h.n_allocs);
   if (fread(sizes.data(), 8, sizes.size(), f) != sizes.size()) { fclose(f); return fail(-3, "truncated packed engine (sizes)"); }
-  if (h.quant_flags & ~(PTTS_QUANT_ATTENTION | PTTS_QUANT_FFN | PTTS_CODEC_BF16 | PTTS_CODEC_FP8 | PTTS_LM_BF16)) {
+  if (h.quant_flags & ~(PTTS_QUANT_ATTENTION | PTTS_QUANT_FFN | PTTS_CODEC_BF16 | PTTS_CODEC_FP8 | PTTS_LM_BF16 | PTTS_CODEC_SPLIT)) {
     fclose(f);
     return fail(-3, "packed engine carries unknown weight-format flags");
   }
@@ -2308,6 +2343,7 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
   if (e->codec_bf16) return mimi_enqueue_h(st, e, s, d_latent, d_pcm);
   const ptts_config &c = e->cfg;
   bind_engine(e);
+  struct SplitScope { SplitScope(bool on) { g_use_split = on; } ~SplitScope() { g_use_split = false; } } split_scope(e->codec_split);
   struct LdsScope { LdsScope(int t) { g_lds_target = t; } ~LdsScope() { g_lds_target = 0; } } lds_scope(e->opt_codec_lds_target);
   const int B = s->B, C = c.m_dim, CF = C / 16, LF = c.ldim / 16, st16 = c.upsample_stride;
   SITE("mimi.prologue");  // de-normalise + quantizer 1x1 conv + depthwise x16 upsample + RoPE table: one launch

@@ -20,3 +20,10 @@ void pack_weight_f8(hipStream_t st, const float *src, void *dst, float *wscale, 
 void launch_gemm_f8(hipStream_t st, const GemmArgs &a, unsigned dyn_lds);
 // max |x| over n bf16 values (calibration of the static activation scales), atomically max-ed into *out (as float bits)
 void amax_bf16(hipStream_t st, const void *x, long n, float *out);
+
+// ---- ptts_split.hip: codec GEMMs on error-compensated ("split") bf16 (PTTS_CODEC_SPLIT) ----------------------------------
+// every register-staged configuration of gemm_kernel<.., WF = 3> (cfg = index into ptts.hip's table; LDS-staged ones do not exist)
+void launch_gemm_split(hipStream_t st, const GemmArgs &a, int pre, int cfg, unsigned dyn_lds);
+bool split_cfg(int cfg);
+// fp32 packed image [NT][KF][64][4] -> hi = bf16(w) and lo = bf16(w - hi) images, each [NT][KF/2][64][8]
+void pack_weight_split(hipStream_t st, const float *src, void *hi, void *lo, int NT, int KF);

@@ -79,34 +79,29 @@ void amax_bf16(hipStream_t st, const void *x, long n, float *out) {
 }
 
 // ---- epilogue of one 16x16 tile ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void f8_store(const GemmArgs &a, int par, size_t o, f32x4 v) {
+  if (a.yf8) *(unsigned *)((uint8_t *)a.Y + par * a.Ydstride + o) = to_f8x4(v * a.yinv);
+  else *(bf16x4 *)((__bf16 *)a.Y + par * a.Ydstride + o) = to_bf16x4(v);
+}
 __device__ __forceinline__ void gemm_f8_epilogue(const GemmArgs &a, f32x4 acc, int nt, int mt, int lane, int par) {
   const int ml = lane & 15, g = lane >> 4;
   const int m = 16 * mt + ml;
   const int n0 = 16 * nt + 4 * g;
   acc = acc * (*(const f32x4 *)(a.wscale + n0) * a.xs);
   if (a.bias) acc += *(const f32x4 *)(a.bias + n0);
-  auto store = [&](size_t o, f32x4 v) {
-    if (a.yf8) *(unsigned *)((uint8_t *)a.Y + par * a.Ydstride + o) = to_f8x4(v * a.yinv);
-    else *(bf16x4 *)((__bf16 *)a.Y + par * a.Ydstride + o) = to_bf16x4(v);
-  };
-  switch (a.epi) {
-    case EPI_STORE: {
-      const size_t o = fmh_off(m, n0, a.YF);
-      if (a.Yraw) *(bf16x4 *)((__bf16 *)a.Yraw + par * a.Yrawdstride + o) = to_bf16x4(acc);
-      store(o, act4(acc, a.act));
-    } break;
-    case EPI_RES: {
-      const f32x4 rv = from_bf16x4(*(const bf16x4 *)((const __bf16 *)a.R + par * a.Rdstride + fmh_off(m, n0, a.RF)));
-      store(fmh_off(m, n0, a.YF), act4(rv + acc, a.act));
-    } break;
-    case EPI_CONVTR: {
-      const int j = n0 / a.cout;
-      const int n = n0 - j * a.cout;
-      const size_t o = fmh_off((size_t)m * a.stride + j, n, a.YF);
-      if (a.Yraw) *(bf16x4 *)((__bf16 *)a.Yraw + par * a.Yrawdstride + o) = to_bf16x4(acc);
-      store(o, act4(acc, a.act));
-    } break;
-    default: break;
+  if (a.epi == EPI_STORE) {
+    const size_t o = fmh_off(m, n0, a.YF);
+    if (a.Yraw) *(bf16x4 *)((__bf16 *)a.Yraw + par * a.Yrawdstride + o) = to_bf16x4(acc);
+    f8_store(a, par, o, act4(acc, a.act));
+  } else if (a.epi == EPI_RES) {
+    const f32x4 rv = from_bf16x4(*(const bf16x4 *)((const __bf16 *)a.R + par * a.Rdstride + fmh_off(m, n0, a.RF)));
+    f8_store(a, par, fmh_off(m, n0, a.YF), act4(rv + acc, a.act));
+  } else if (a.epi == EPI_CONVTR) {
+    const int j = n0 / a.cout;
+    const int n = n0 - j * a.cout;
+    const size_t o = fmh_off((size_t)m * a.stride + j, n, a.YF);
+    if (a.Yraw) *(bf16x4 *)((__bf16 *)a.Yraw + par * a.Yrawdstride + o) = to_bf16x4(acc);
+    f8_store(a, par, o, act4(acc, a.act));
   }
 }
 

@@ -83,7 +83,10 @@ struct GemmArgs {
   const float *wscale;
   // weight image format: 0 = fp32 (W), 1 = int8 (Wq, above), 2 = bf16 (Wq reinterpreted as __bf16, packed [NT][KF/2][64][8]:
   // lane (g, n) holds W[n][32 kb + 4 g + 0..3] and W[n][32 kb + 16 + 4 g + 0..3], i.e. the lane's operands of the two fp32
-  // k-fragments 2 kb and 2 kb + 1, so the activation operand is the two fp32 fragments converted in registers, no shuffle)
+  // k-fragments 2 kb and 2 kb + 1, so the activation operand is the two fp32 fragments converted in registers, no shuffle),
+  // 3 = split bf16 (error-compensated: Wq = the bf16 image of hi = bf16(w), W reinterpreted = the bf16 image of
+  // lo = bf16(w - hi), both in the format-2 layout; the kernel splits the fp32 activation the same way in registers and
+  // accumulates hi*hi + hi*lo + lo*hi in fp32 on v_mfma_f32_16x16x32_bf16: ~2^-16 relative per product instead of bf16's 2^-8)
   int wfmt;
   int swz;  // XCD-aware workgroup -> tile mapping (tile_of_block)
   int krot;  // Linear layers, K-split tiles: workgroup bx starts its K loop at chunk bx % nchunks, so the column blocks that
@@ -320,7 +323,8 @@ template <int TN, int TM, int WK, int WN, int WM, int PRE, int WF = 0>
 __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
   if constexpr (PTTS_ABLATE & 128) return;  // ablation 128 (timing only): empty kernels = launch + boundary cost
   constexpr bool Q8 = WF == 1;   // int8 weights, fp32 activations, fp32 MFMA
-  constexpr bool B16 = WF == 2;  // bf16 weights, activations rounded to bf16 in registers, v_mfma_f32_16x16x32_bf16
+  constexpr bool SPL = WF == 3;  // split bf16 (hi + lo images, three bf16 MFMAs per block): see GemmArgs::wfmt
+  constexpr bool B16 = WF == 2 || SPL;  // bf16 weights, activations rounded to bf16 in registers, v_mfma_f32_16x16x32_bf16
   constexpr int NW = WK * WN * WM;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
     int nt = nt0 + i < a.NT ? nt0 + i : a.NT - 1;
-    wb[i] = a.W + (size_t)nt * a.KF * 256 + lane * 4;
+    wb[i] = SPL ? (const float *)((const uint8_t *)a.W + (size_t)nt * a.KF * 512 + lane * 16) : a.W + (size_t)nt * a.KF * 256 + lane * 4;
     wqb[i] = Q8 ? a.Wq + (size_t)nt * a.KF * 256 + lane * 16 : B16 ? a.Wq + (size_t)nt * a.KF * 512 + lane * 16 : nullptr;
   }
   int mtc[TM], tin[TM], bT[TM];
@@ -489,6 +493,7 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
   constexpr int KDIV = (TN * TM == 1) ? PTTS_KSPLIT_DIV1 : PTTS_KSPLIT_DIV;
   constexpr int U0 = (WK > 1) ? (U00 / KDIV >= 1 ? U00 / KDIV : 1) : U00;
   constexpr int U = (Q8 && U0 < 4) ? 4 : (B16 && U0 < 2) ? 2 : U0;  // int8 / bf16 weights arrive four / two k-fragments per load
+  // (split bf16: a chunk of U fragments parks U / 2 hi blocks in slots 0 .. U/2 - 1 and U / 2 lo blocks behind them)
   auto load_chunk = [&](auto uc, int kf, f32x4 (*w)[TN], f32x4 (*x)[TM]) {
     constexpr int UU = decltype(uc)::value;
     if (a.ntaps == 1) cf = kf;  // a Linear's fragments are addressed by k alone (chunks may come in rotated order)
@@ -507,8 +512,14 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
         } else if constexpr (B16) {
           // eight bf16 of fragments kf+u, kf+u+1 (kf + u even), parked in slot u/2
           if (u % 2 == 0) {
-            const i32x4 raw = __builtin_nontemporal_load((const i32x4 *)(wqb[i] + (size_t)((kf + u) >> 1) * 1024));
-            w[u / 2][i] = __builtin_bit_cast(f32x4, raw);
+            if constexpr (WK > 1) {
+              w[u / 2][i] = __builtin_bit_cast(f32x4, __builtin_nontemporal_load((const i32x4 *)(wqb[i] + (size_t)((kf + u) >> 1) * 1024)));
+              if constexpr (SPL)
+                w[UU / 2 + u / 2][i] = __builtin_bit_cast(f32x4, __builtin_nontemporal_load((const i32x4 *)((const uint8_t *)wb[i] + (size_t)((kf + u) >> 1) * 1024)));
+            } else {  // 2-D tilings re-read a weight tile from several row blocks: plain (cached) loads
+              w[u / 2][i] = *(const f32x4 *)(wqb[i] + (size_t)((kf + u) >> 1) * 1024);
+              if constexpr (SPL) w[UU / 2 + u / 2][i] = *(const f32x4 *)((const uint8_t *)wb[i] + (size_t)((kf + u) >> 1) * 1024);
+            }
           }
         } else if constexpr (WK > 1) w[u][i] = __builtin_nontemporal_load((const f32x4 *)(wb[i] + (size_t)(kf + u) * 256));
         else w[u][i] = *(const f32x4 *)(wb[i] + (size_t)(kf + u) * 256);
@@ -570,6 +581,20 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
           for (int j = 0; j < TM; ++j) {
             const bf16x4 lo = to_bf16x4(x[u - 1][j]), hi = to_bf16x4(x[u][j]);
             const bf16x8 xb = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            if constexpr (SPL) {
+              // residual halves of the activation: x - bf16(x) is exact in fp32 and rounds to bf16 with 2^-17 relative error
+              const bf16x4 rl = to_bf16x4(x[u - 1][j] - from_bf16x4(lo)), rh = to_bf16x4(x[u][j] - from_bf16x4(hi));
+              const bf16x8 xr = __builtin_shufflevector(rl, rh, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+              for (int i = 0; i < TN; ++i) {
+                const bf16x8 wh = __builtin_bit_cast(bf16x8, w[u / 2][i]), wl = __builtin_bit_cast(bf16x8, w[UU / 2 + u / 2][i]);
+                // small terms first, the hi * hi term last
+                acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xb, acc[i][j][0], 0, 0, 0);
+                acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xr, acc[i][j][0], 0, 0, 0);
+                acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xb, acc[i][j][0], 0, 0, 0);
+              }
+              continue;
+            }
 #pragma unroll
             for (int i = 0; i < TN; ++i)
               acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[u / 2][i]), xb, acc[i][j][0], 0, 0, 0);

@@ -155,7 +155,7 @@ class Engine:
     """Weights of one model on one GPU + entry points of the hot path."""
 
     # PTTS_QUANT_* / PTTS_CODEC_BF16 / PTTS_CODEC_FP8 / PTTS_LM_BF16 (include/ptts.h)
-    QUANT_GROUPS = {"attention": 1, "ffn": 2, "codec_bf16": 4, "codec_fp8": 8, "lm_bf16": 16}
+    QUANT_GROUPS = {"attention": 1, "ffn": 2, "codec_bf16": 4, "codec_fp8": 8, "lm_bf16": 16, "codec_split": 32}
 
     def __init__(self, cfg: Config, weights: dict, device: str | torch.device = "cuda:0",
                  quantize_groups: set | frozenset | None = None, _packed: str | None = None):

@@ -123,6 +123,10 @@ static void sweep(const char *name, int M, int N, int K, int ntaps, int T) {
   run<2, 4, 1, 2, 2>(r, M, N, K, ntaps, T); run<2, 4, 1, 1, 4>(r, M, N, K, ntaps, T); run<1, 4, 1, 1, 4>(r, M, N, K, ntaps, T);
   run<1, 1, 1, 1, 4>(r, M, N, K, ntaps, T); run<2, 2, 1, 2, 2>(r, M, N, K, ntaps, T); run<1, 4, 1, 2, 2>(r, M, N, K, ntaps, T);
   run<1, 2, 1, 2, 2>(r, M, N, K, ntaps, T); run<2, 4, 2, 2, 1>(r, M, N, K, ntaps, T);
+  // round 3: fat register tiles (16 accumulator tiles per wave: twice the MFMAs per operand byte of the 2x4 tile)
+  run<4, 4, 1, 2, 2>(r, M, N, K, ntaps, T); run<4, 4, 1, 1, 4>(r, M, N, K, ntaps, T); run<2, 8, 1, 1, 4>(r, M, N, K, ntaps, T);
+  run<4, 4, 1, 2, 1>(r, M, N, K, ntaps, T); run<4, 4, 1, 1, 2>(r, M, N, K, ntaps, T); run<2, 8, 1, 2, 2>(r, M, N, K, ntaps, T);
+  run<4, 2, 1, 2, 2>(r, M, N, K, ntaps, T); run<2, 4, 1, 2, 4>(r, M, N, K, ntaps, T); run<4, 4, 1, 2, 4>(r, M, N, K, ntaps, T);
   std::sort(r.begin(), r.end(), [](const Res &a, const Res &b) { return a.us < b.us; });
   double fl = 2.0 * M * N * (double)K * ntaps;
   printf("%-28s M=%-6d N=%-5d K=%dx%-4d |", name, M, N, ntaps, K);
@@ -150,6 +154,15 @@ int main(int argc, char **argv) {
     run_ldsp<4, 8, 2>(r, 6 * R, 640, 256, 2, 96);    // convtr2, persistent
     run_ldsp<4, 4, 3>(r, R, 2048, 512, 1, 16);       // mimi.ff1, persistent
     for (auto &x : r) printf("%s %.1f us (%dx%d)\n", x.cfg.c_str(), x.us, x.gx, x.gy);
+    return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "codec")) {  // only the codec shapes (round-3 fat-tile experiment)
+    const int R = 1024;
+    sweep("mimi.qkv", R, 1536, 512, 1, 16); sweep("mimi.ff1", R, 2048, 512, 1, 16); sweep("mimi.ff2", R, 512, 2048, 1, 16);
+    sweep("seanet.conv0", R, 512, 512, 7, 16); sweep("seanet.convtr1", R, 1536, 512, 2, 16);
+    sweep("seanet.res1a", 6 * R, 128, 256, 3, 96); sweep("seanet.convtr2", 6 * R, 640, 256, 2, 96);
+    sweep("seanet.res2a", 30 * R, 64, 128, 3, 480); sweep("seanet.convtr3", 30 * R, 256, 128, 2, 480);
+    sweep("seanet.res3a", 120 * R, 32, 64, 3, 1920);
     return 0;
   }
   const int Bs[] = {64};
