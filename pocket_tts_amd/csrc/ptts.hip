@@ -747,7 +747,7 @@ static void launch_gemm(hipStream_t st, const GemmArgs &a_in, int pre) {
 // k3 conv + ELU + 1x1 conv + skip of a SEANet residual block in one launch (a = the k3 conv's arguments with Y / R
 // already describing the block's output and skip input)
 static bool resblock_fusable(const Lin &A, const Lin &Bl, int MT) {
-  return !(g_use_split && A.wsh) && !A.wq && !Bl.wq && A.bias && Bl.bias && Bl.ntaps == 1 && Bl.KF == A.NT && A.KF % 2 == 0 && MT >= 4 &&
+  return !A.wq && !Bl.wq && A.bias && Bl.bias && Bl.ntaps == 1 && Bl.KF == A.NT && A.KF % 2 == 0 && MT >= 4 &&
          ((A.NT == 2 && Bl.NT == 4) || (A.NT == 4 && Bl.NT == 8));
 }
 static void launch_resblock(hipStream_t st, GemmArgs a, const Lin &Bl) {
@@ -1695,7 +1695,10 @@ static int ensure_flow(ptts_engine *e, ptts_lm_state *s, int steps, hipStream_t 
                     "(they hold the old AdaLN / exchange buffers)");
   const ptts_config &c = e->cfg;
   const int FDF = c.flow_dim / 16;
-  s->flow_rt = 1;  // one cluster per 16 rows: rows are independent, the clusters' weight re-reads stay in L2
+  // row tiles per cluster.  1 (default): one cluster per 16 rows, the clusters' weight re-reads stay in L2 / Infinity Cache.
+  // 2 (PTTS_FLOW_RT=2, A/B knob): half the clusters, half the weight fetches and CUs, twice the exchange payload per phase.
+  static const int rt_env = [] { const char *v = getenv("PTTS_FLOW_RT"); return v ? atoi(v) : 1; }();
+  s->flow_rt = (rt_env == 2 && s->MT >= 2) ? 2 : 1;
   s->flow_ng = cdiv(s->MT, s->flow_rt);
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -1748,7 +1751,8 @@ static void launch_flow_cluster(hipStream_t st, ptts_engine *e, ptts_lm_state *s
                lsd_steps * (wbytes + 4.0 * s->B * 16.0 * e->adaln.NT), flops);
   const int kpw = cdiv(std::max(FDF, LF), FLOW_WORKERS);
   s->coop_wgs = std::max(s->coop_wgs, fa.NCL * FDF);
-  launch_flow_rt<1>(st, fa, kpw);
+  if (s->flow_rt == 2) launch_flow_rt<2>(st, fa, kpw);
+  else launch_flow_rt<1>(st, fa, kpw);
 }
 
 
@@ -1918,19 +1922,28 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
   Scratch &sc = s->dec;
   s->coop_wgs = 0;
   const float *tcomb = e->tcomb[lsd_steps];
-  SITE("lm.prep");
-  {
-    ProfScope ps(st, "prep_lm", 16.0 * B * c.ldim, 0);
-    const int nb_prep = cdiv(MT * LF * 64, 256);
-    prep_lm_kernel<<<nb_prep + cdiv(B * 32, 256), 256, 0, st>>>(d_latent_in ? d_latent_in : s->lat_prev, e->bos, d_noise,
-                                                                 s->xlat, s->lat, s->latfm, B, c.ldim, MT, s->rng_std,
-                                                                 s->rng_seed, s->rng_ctr, nb_prep,
-                                                                 RopeArgs{s->offset, e->freq_lm, sc.rope, B, 1});
+  SITE("lm.prep");  // BOS substitution + input_linear + noise / LSD start point + RoPE table: one launch
+  if (e->in_linear.w && !e->in_linear.bias && e->in_linear.KF == LF) {
+    ProfScope ps(st, "prep_in", 16.0 * B * c.ldim + 4.0 * (D * c.ldim + B * D), 2.0 * B * D * c.ldim);
+    const int nb_gemm = cdiv(DF * MT, 4), nb_prep = cdiv(MT * LF * 64, 256);
+    prep_in_kernel<<<nb_gemm + nb_prep + cdiv(B * 32, 256), 256, 0, st>>>(
+        d_latent_in ? d_latent_in : s->lat_prev, e->bos, d_noise, e->in_linear.w, sc.x, s->lat, s->latfm, B, c.ldim, MT, DF, s->rng_std,
+        s->rng_seed, s->rng_ctr, nb_gemm, nb_prep, RopeArgs{s->offset, e->freq_lm, sc.rope, B, 1});
+  } else {
+    {
+      ProfScope ps(st, "prep_lm", 16.0 * B * c.ldim, 0);
+      const int nb_prep = cdiv(MT * LF * 64, 256);
+      prep_lm_kernel<<<nb_prep + cdiv(B * 32, 256), 256, 0, st>>>(d_latent_in ? d_latent_in : s->lat_prev, e->bos, d_noise,
+                                                                   s->xlat, s->lat, s->latfm, B, c.ldim, MT, s->rng_std,
+                                                                   s->rng_seed, s->rng_ctr, nb_prep,
+                                                                   RopeArgs{s->offset, e->freq_lm, sc.rope, B, 1});
+    }
+    SITE("lm.in_linear");
+    GemmArgs a0 = mk_gemm(e->in_linear, s->xlat, LF, MT, B);
+    a0.Y = sc.x; a0.YF = DF;
+    launch_gemm(st, a0, PRE_NONE);
   }
-  SITE("lm.in_linear");
-  GemmArgs a = mk_gemm(e->in_linear, s->xlat, LF, MT, B);
-  a.Y = sc.x; a.YF = DF;
-  launch_gemm(st, a, PRE_NONE);
+  GemmArgs a;
   if (lm_cluster_ok(e, s) && s->lexch) {
     SITE("lm.cluster");
     launch_lm_cluster(st, e, s, sc);
@@ -1942,6 +1955,7 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
   a.epi = EPI_HEAD; a.Y = s->ce; a.YF = FDF; a.head_nt = FDF; a.eos_thr = eos_thr;
   a.eos_logit = s->eos_logit; a.is_eos = s->is_eos;
   a.eos_logit2 = d_eos_logit; a.is_eos2 = d_is_eos;  // caller's buffers are written by the epilogue itself
+  a.tail_offset = s->offset; a.tail_ctr = s->rng_ctr; a.tail_active = s->active;  // the step's bookkeeping rides along (was a launch)
   const bool silu_in_head = lsd_steps == 1;  // s->ce then holds silu(t_emb + cond) and the modulation GEMM loads it as is
   if (silu_in_head) { a.act = ACT_SILU; a.prevec = tcomb; }
   launch_gemm(st, a, PRE_LNFOLD);
@@ -1995,11 +2009,6 @@ static int lm_step_enqueue(hipStream_t st, ptts_engine *e, ptts_lm_state *s, con
     a.epi = EPI_LATENT; a.lat = s->lat; a.ldim = c.ldim; a.inv_steps = 1.0f / (float)lsd_steps; a.Y = s->latfm; a.YF = LF;
     if (i == lsd_steps - 1) { a.lat_out1 = s->lat_prev; a.lat_out2 = d_latent_out; }  // next step's input + caller's copy
     launch_gemm(st, a, PRE_LNMOD);
-  }
-  SITE("lm.tail");
-  {
-    ProfScope ps(st, "step_tail", 8.0 * B, 0);
-    step_tail_kernel<<<cdiv(B, 256), 256, 0, st>>>(s->offset, B, 1, s->rng_ctr, s->active);
   }
   SITE("");
   return 0;
@@ -2400,6 +2409,9 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
       a.Xdstride = s->c_stride[i]; a.T = Tout; a.par = s->frame; a.act = ACT_ELU;
       a.R = s->craw[i]; a.Rdstride = 0; a.RF = cout / 16; a.act2 = ACT_ELU;
       a.Y = s->sbuf[i]; a.Ydstride = s->s_stride[i]; a.YF = cout / 16;
+      // a split-bf16 engine keeps the FUSED fp32 residual blocks: the unfused split pair is slower (stage 3: 34 + 35 us
+      // against 43 us fused, stage 2: 25 + 21 against 32; gpurun_out r3 profile), the block is bound by its activations
+      a.W = e->res_a[i].w; a.Wq = nullptr; a.wfmt = 0;
       launch_resblock(st, a, e->res_b[i]);
       xin = s->sbuf[i];
       xds = s->s_stride[i];

@@ -143,6 +143,11 @@ struct GemmArgs {
   uint8_t *is_eos, *is_eos2;
   float eos_thr;
   int head_nt;  // n-tile holding the EOS row
+  // end-of-step bookkeeping done by the EOS row's threads (one per sequence, so exactly once): offset[m] += 1 for active rows
+  // (increment_steps, stateful_module.py:19-26) and, by row 0, the step counter.  Nothing after the head GEMM reads a position,
+  // and the flow cluster / the next step's prologue only need the counter to have moved once per step.
+  int *tail_offset, *tail_ctr;
+  const int *tail_active;
   // EPI_LATENT
   float *lat;  // plain [M][ldim], updated in place
   float *lat_out1, *lat_out2;  // optional extra copies of the updated latent (state's next input, caller's buffer)
@@ -283,6 +288,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 acc, int 
         if (a.eos_logit2) a.eos_logit2[m] = acc.x;
         if (a.is_eos) a.is_eos[m] = fl;
         if (a.is_eos2) a.is_eos2[m] = fl;
+        if (a.tail_offset && (!a.tail_active || a.tail_active[m])) a.tail_offset[m] += 1;
+        if (a.tail_ctr && m == 0) *a.tail_ctr += 1;
       }
     } break;
     case EPI_LATENT: {
@@ -1290,6 +1297,61 @@ static __global__ void prep_lm_kernel(const float *lat_in, const float *bos, con
     }
   }
   *(f32x4 *)(x_fm + (size_t)i * 4) = v;
+  *(f32x4 *)(lat_fm + (size_t)i * 4) = z;
+  if (m < B) *(f32x4 *)(lat + (size_t)m * ldim + k) = z;
+}
+
+// Step prologue of the FlowLM + input_linear in ONE launch (round 3): the K = ldim (32) GEMM  x = input_linear(where(isnan(z), bos, z))
+// (reference flow_lm.py:121-122) is one wave per 16x16 output tile reading the plain latent rows directly (BOS substitution
+// on load), beside the noise / LSD start point writes and the step's RoPE table of prep_lm_kernel.  As its own K-split GEMM
+// launch the tiny product cost ~10 us of a step (8 waves splitting two k-fragments) plus a dependent launch.
+static __global__ __launch_bounds__(256) void prep_in_kernel(const float *lat_in, const float *bos, const float *noise, const float *w_in,
+                                                             float *x_out, float *lat, float *lat_fm, int B, int ldim, int MT, int DF,
+                                                             float rng_std, unsigned long long rng_seed, const int *rng_ctr,
+                                                             int nb_gemm, int nb_prep, RopeArgs rope) {
+  const int LF = ldim / 16;
+  if ((int)blockIdx.x < nb_gemm) {
+    const int lane = threadIdx.x & 63, tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= DF * MT) return;
+    const int nt = tile % DF, mt = tile / DF;
+    const int m = 16 * mt + (lane & 15), g = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kf = 0; kf < LF; ++kf) {
+      const int k = 16 * kf + 4 * g;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < B) {
+        v = *(const f32x4 *)(lat_in + (size_t)m * ldim + k);
+        const f32x4 b = *(const f32x4 *)(bos + k);
+        v.x = v.x != v.x ? b.x : v.x; v.y = v.y != v.y ? b.y : v.y; v.z = v.z != v.z ? b.z : v.z; v.w = v.w != v.w ? b.w : v.w;
+      }
+      const f32x4 w = *(const f32x4 *)(w_in + (((size_t)nt * LF + kf) * 64 + lane) * 4);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c], v[c], acc, 0, 0, 0);
+    }
+    *(f32x4 *)(x_out + (((size_t)mt * DF + nt) * 64 + lane) * 4) = acc;
+    return;
+  }
+  if ((int)blockIdx.x >= nb_gemm + nb_prep) {
+    rope_table_entry(rope, (blockIdx.x - nb_gemm - nb_prep) * blockDim.x + threadIdx.x);
+    return;
+  }
+  const int i = (blockIdx.x - nb_gemm) * blockDim.x + threadIdx.x;
+  if (i >= MT * LF * 64) return;
+  const int lane = i & 63, f = i >> 6;
+  const int kf = f % LF, mt = f / LF;
+  const int m = 16 * mt + (lane & 15), k = 16 * kf + 4 * (lane >> 4);
+  f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  if (m < B) {
+    if (noise) {
+      z = *(const f32x4 *)(noise + (size_t)m * ldim + k);
+    } else if (rng_std > 0.f) {
+      const unsigned ctr = (unsigned)*rng_ctr, base = (unsigned)(m * ldim + k);
+      z.x = rng_std * counter_normal(rng_seed, ctr, base + 0);
+      z.y = rng_std * counter_normal(rng_seed, ctr, base + 1);
+      z.z = rng_std * counter_normal(rng_seed, ctr, base + 2);
+      z.w = rng_std * counter_normal(rng_seed, ctr, base + 3);
+    }
+  }
   *(f32x4 *)(lat_fm + (size_t)i * 4) = z;
   if (m < B) *(f32x4 *)(lat + (size_t)m * ldim + k) = z;
 }

@@ -346,7 +346,7 @@ def test_tuned_table_export_import_roundtrip(tmp_path, monkeypatch):
     buf = C.create_string_buffer(1 << 20)
     n1 = eng.lib.ptts_tune_export(eng.handle, buf, len(buf))
     table1 = buf.value.decode()
-    assert n1 > 0 and len(table1.splitlines()) >= 20
+    assert n1 > 0 and len(table1.splitlines()) >= 18  # 19 shapes since input_linear rides in the step prologue (round 3)
     eng.lib.ptts_tune_clear(eng.handle)
     eng._tuned.clear()
     assert eng.tune(5) == ""  # served from the cache file: nothing is measured
