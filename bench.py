@@ -343,19 +343,38 @@ def tune_table_id(eng) -> str:
     return hashlib.sha256("\n".join(sorted(eng._tune_table())).encode()).hexdigest()[:12]
 
 
+PMC_FILE = "r03_pmc_traffic.json"     # tools/profile_round.sh -> profiles/ (FETCH_SIZE / WRITE_SIZE passes of this round's build)
+STATS_FILE = "r03_b64_kernel_stats.csv"  # rocprofv3 --kernel-trace --stats of the headline command
+
+
 def pmc_traffic(name, table_id):
-    """HBM bytes per launch of `name` from the committed PMC passes (profiles/r02_pmc_traffic.json: rocprofv3 --pmc
+    """HBM bytes per launch of `name` from the committed PMC passes (profiles/r03_pmc_traffic.json: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 calibration).  PMC counters cannot be
     read from inside this process, so the file is a replay; it is only used when it was measured on the SAME tile
     table as this run (its `tune_table_id` stamp), else None."""
     try:
-        with open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")) as f:
+        with open(os.path.join(REPO, "profiles", PMC_FILE)) as f:
             d = json.load(f)
         if d.get("tune_table_id") != table_id:
             return None
         return d["kernels"][name]["traffic_bytes_per_launch"]
     except Exception:
         return None
+
+
+def rocprof_avg_us(kernel_substr):
+    """average duration of a kernel over the WHOLE pipelined bench run from the committed rocprofv3 --stats summary (the
+    cross-check SURVEY 8d asks for: both streams running, contexts 159-283), or None"""
+    import csv
+
+    try:
+        with open(os.path.join(REPO, "profiles", STATS_FILE)) as f:
+            for r in csv.DictReader(f):
+                if kernel_substr in r["Name"]:
+                    return float(r["AverageNs"]) / 1e3
+    except Exception:
+        pass
+    return None
 
 
 def roofline_of(rows, table_id):
@@ -374,6 +393,11 @@ def roofline_of(rows, table_id):
     common = dict(kernel=name, site=site, traffic=pmc_traffic(name, table_id), avg_us=avg_s * 1e6, launches=k["count"],
                   algorithmic_bytes_per_launch=k["bytes"] / k["count"], flops_per_launch=k["flops"] / k["count"],
                   timing="HIP events around each launch on its own stream (eager steps at mid-utterance context)")
+    if name.startswith("attn_decode"):
+        # cross-check against the committed rocprofv3 summary: its average is over the whole PIPELINED run (codec stream
+        # co-running, contexts up to 283 keys), so it is slower than the isolated eager launch timed here
+        common["rocprof_pipelined_avg_us"] = rocprof_avg_us("attn_decode2_kernel")
+        common["rocprof_file"] = "profiles/" + STATS_FILE
     if tfs / MFMA_F32_PEAK_TF > gbs / HBM_PEAK_GBS:
         return dict(bound="mfma", achieved=tfs, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=tfs / MFMA_F32_PEAK_TF, **common)
     return dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, **common)

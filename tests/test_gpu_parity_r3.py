@@ -124,3 +124,41 @@ def test_permlane_swap_inline_asm(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     print(r.stdout)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_24l_batch32_vs_oracle():
+    """BASELINE config #4 per GPU (24-layer model, 32 utterances) against the numpy ORACLE (until now
+    this model met the oracle at batch 1 only and batch 32 through HIP-vs-HIP properties): voice + text prefill of the
+    bench's shapes (126 + 32), three decode steps with noise, latents / EOS logits / PCM."""
+    from oracle import np_oracle as O
+
+    cfg, W = synth_weights("24l")
+    eng = get_engine("24l")
+    B, Tv, Tt, ns = 32, 126, 32, 3
+    rng = np.random.default_rng(2432)
+    voice = (rng.standard_normal((B, Tv, eng.D)) * 0.1).astype(np.float32)
+    text = (rng.standard_normal((B, Tt, eng.D)) * 0.3).astype(np.float32)
+    noise = (rng.standard_normal((ns, B, eng.ldim)) * 0.7 ** 0.5).astype(np.float32)
+    lm, dec = O.FlowLM(cfg, W), O.MimiDecoder(cfg, W)
+    ost, oms = lm.init_state(B, Tv + Tt + ns), dec.init_state(B, ns)
+    st, ms = eng.new_lm_state(B, Tv + Tt + ns), eng.new_mimi_state(B)
+    try:
+        for e in (voice, text):
+            lm.prefill(ost, e)
+            eng.lm_prefill(st, dev(e))
+        xo = np.full((B, eng.ldim), np.nan, np.float32)
+        for i in range(ns):
+            xo, lo, eo = lm.decode_step(ost, xo, noise[i], 1, -4.0)
+            po = dec.decode(oms, xo)
+            xg, lg, fg = eng.lm_decode_step(st, None, dev(noise[i]), 1, -4.0)
+            pg = eng.mimi_decode(ms, xg)
+            torch.cuda.synchronize()
+            assert _maxerr(xg.cpu().numpy(), xo) < ATOL, (i, "latent")
+            assert _maxerr(lg.cpu().numpy(), lo) < 1e-3, (i, "eos logit")
+            sure = np.abs(lo + 4.0) > 1e-3
+            assert np.array_equal((fg.cpu().numpy() > 0)[sure], eo[sure]), (i, "eos decision")
+            assert _maxerr(pg.cpu().numpy(), po) < ATOL, (i, "pcm")
+        assert not st.error()
+    finally:
+        st.close()
+        ms.close()

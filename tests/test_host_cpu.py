@@ -130,6 +130,9 @@ def test_pmc_tool_labels_match_the_profiler_labels():
     assert n("void gemm_kernel<1, 1, 4, 1, 1, 4, false>(GemmArgs)") == "gemm<1,1,4,1,1>+lnmod"
     assert n("void gemm_kernel<2, 2, 4, 1, 1, 2, false>(GemmArgs)") == "gemm<2,2,4,1,1>+addsilu"
     assert n("void gemm_kernel<1, 2, 4, 1, 1, 3, true>(GemmArgs)") == "gemm<1,2,4,1,1>+ln+q8"
+    assert n("void gemm_kernel<1, 2, 4, 1, 1, 3, 1>(GemmArgs)") == "gemm<1,2,4,1,1>+ln+q8"  # round 3: the flag became an int
+    assert n("void gemm_kernel<2, 2, 4, 1, 1, 0, 0>(GemmArgs)") == "gemm<2,2,4,1,1>"
+    assert n("void gemm_kernel<1, 1, 4, 1, 1, 0, 2>(GemmArgs)") == "gemm<1,1,4,1,1>+b16"
     assert n("void gemm_lds_kernel<4, 4, 2, 3, 2>(GemmArgs)") == "gemm_lds<4,4,2>+ln"
     assert n("void gemm_lds_kernel<4, 2, 2, 0, 2>(GemmArgs)") == "gemm_lds<4,2,2>"
     assert n("void attn_decode_kernel<1, true>(AttnArgs)") == "attn_decode"

@@ -15,10 +15,12 @@ PRE = {0: "", 1: "+elu", 2: "+addsilu", 3: "+ln", 4: "+lnmod"}
 
 
 def norm(name):
-    m = re.search(r"gemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false)>", name)
+    # 7th template argument = weight format (round 2: bool Q8; round 3: int WF: 0 fp32, 1 int8, 2 bf16)
+    m = re.search(r"gemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (true|false|\d+))?>", name)
     if m:
         a = [int(x) for x in m.groups()[:6]]
-        return "gemm<%d,%d,%d,%d,%d>%s%s" % (*a[:5], PRE.get(a[5], ""), "+q8" if m.group(7) == "true" else "")
+        wf = {"true": "+q8", "1": "+q8", "2": "+b16"}.get(m.group(7) or "0", "")
+        return "gemm<%d,%d,%d,%d,%d>%s%s" % (*a[:5], PRE.get(a[5], ""), wf)
     m = re.search(r"gemm_lds_kernel<(\d+), (\d+), (\d+), (\d+)(?:, (\d+))?(?:, (\d+))?>", name)
     if m:
         if m.group(6) and int(m.group(6)) > 0:  # fused residual block: bench.py's profiler calls it resblock<BNT,NT2>

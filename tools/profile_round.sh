@@ -1,8 +1,12 @@
 #!/bin/bash
 # rocprofv3 evidence of one bench configuration (run on the GPU box through gpurun):
 #   tools/profile_round.sh <tag> [bench.py args ...]
-# writes gpurun_out/<tag>_{stats,fetch,write}/ (kernel trace + stats; PMC FETCH_SIZE; PMC WRITE_SIZE, separate passes as
-# MI355X_MICROARCH.md prescribes) and gpurun_out/<tag>_bench.json (the un-profiled bench line of the same build).
+# writes into gpurun_out/ (copy what is to be judged into profiles/):
+#   <tag>_bench.json          the un-profiled bench line of the same build
+#   <tag>_kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same command (per-kernel calls / total / average)
+#   <tag>_pmc_traffic.json    separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (MI355X_MICROARCH.md: FETCH_SIZE doubled)
+#   <tag>_pmc_sq.json         one --pmc pass of SQ counters (MFMA busy, wave cycles, waits), tools/pmc_sq.py
+# every rocprofv3 run has the program directly after `--`; counters are never combined with other trace domains.
 set -o pipefail
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$PWD}
@@ -10,10 +14,15 @@ out=$root/gpurun_out
 export PTTS_TUNE_CACHE=$root/profiles/tune_cache_mi355x.txt
 cd /tmp && export TMPDIR=/tmp
 python3 $root/bench.py "$@" > $out/${tag}_bench.json 2> $out/${tag}_bench.err || exit 1
+tid=$(python3 -c "import json; print(json.loads(open('$out/${tag}_bench.json').read().strip().split('\n')[-1])['tune_table_id'])")
 rocprofv3 --kernel-trace --stats -d $out/${tag}_stats -o run --output-format csv -- python3 $root/bench.py --quick "$@" > $out/${tag}_stats.log 2>&1 || exit 2
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/${tag}_fetch -o run --output-format csv -- python3 $root/bench.py --steps 12 --warmup 3 --min-seconds 0 --min-utterances 1 --quick "$@" > $out/${tag}_fetch.log 2>&1 || exit 3
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/${tag}_write -o run --output-format csv -- python3 $root/bench.py --steps 12 --warmup 3 --min-seconds 0 --min-utterances 1 --quick "$@" > $out/${tag}_write.log 2>&1 || exit 4
-ls $out/${tag}_stats $out/${tag}_fetch | head -20
-# keep only what is needed (the raw traces are large)
-find $out/${tag}_fetch $out/${tag}_write -name "*kernel_trace.csv" -delete
-du -sh $out/${tag}_*
+cp $(find $out/${tag}_stats -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
+Q="--steps 12 --warmup 3 --min-seconds 0 --min-utterances 1 --quick"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/${tag}_fetch -o run --output-format csv -- python3 $root/bench.py $Q "$@" > $out/${tag}_fetch.log 2>&1 || exit 3
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/${tag}_write -o run --output-format csv -- python3 $root/bench.py $Q "$@" > $out/${tag}_write.log 2>&1 || exit 4
+python3 $root/tools/pmc_traffic.py $out/${tag}_fetch $out/${tag}_write $out/${tag}_pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py $Q $*; one calibration + one timed utterance, contexts 159-283" "$tid" > $out/${tag}_pmc_traffic.txt
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA \
+  --kernel-trace -d $out/${tag}_sq -o run --output-format csv -- python3 $root/bench.py $Q "$@" > $out/${tag}_sq.log 2>&1 || exit 5
+python3 $root/tools/pmc_sq.py $out/${tag}_sq $out/${tag}_pmc_sq.json "rocprofv3 --pmc SQ_* --kernel-trace, bench.py $Q $*" "$tid" > $out/${tag}_pmc_sq.txt
+rm -rf $out/${tag}_stats $out/${tag}_fetch $out/${tag}_write $out/${tag}_sq   # the raw traces are large; the summaries above are what is kept
+head -30 $out/${tag}_pmc_sq.txt; head -12 $out/${tag}_pmc_traffic.txt
