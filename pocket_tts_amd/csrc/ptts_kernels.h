@@ -49,6 +49,17 @@ __device__ __forceinline__ unsigned to_f8x4(f32x4 v) {
 #ifndef PTTS_ABLATE
 #define PTTS_ABLATE 0
 #endif
+// In-kernel time stamps for tests/hip/stamp_gemm.hip only (-DPTTS_STAMP): lane 0 of every wave writes the 100 MHz wall clock
+// at five points of gemm_kernel into a buffer passed in GemmArgs::stamp.  Never defined in the library.
+#ifdef PTTS_STAMP
+#define STAMP(i)                                                                                                               \
+  do {                                                                                                                         \
+    if (a.stamp && (threadIdx.x & 63) == 0)                                                                                    \
+      a.stamp[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
 
 enum { PRE_NONE = 0, PRE_ELU = 1, PRE_ADDSILU = 2, PRE_LNFOLD = 3, PRE_LNMOD = 4 };
 enum { EPI_STORE = 0, EPI_RES, EPI_GATE, EPI_QKV, EPI_HEAD, EPI_LATENT, EPI_CONVTR, EPI_PCM };
@@ -75,6 +86,9 @@ __device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
 // (kernel 2s, stride s == causal conv with 2 taps and s*Cout outputs) of the hot path.
 // ---------------------------------------------------------------------------------------------
 struct GemmArgs {
+#ifdef PTTS_STAMP
+  unsigned long long *stamp;  // tests/hip/stamp_gemm.hip only
+#endif
   // weights, packed [NT][KF][64][4]; bias padded to NT*16
   const float *W, *bias;
   // int8 weight-only variant (Q8 kernels): biased bytes (q + 128) packed [NT][KF/4][64][16] so that one 16-byte load
@@ -329,6 +343,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 acc, int 
 template <int TN, int TM, int WK, int WN, int WM, int PRE, int WF = 0>
 __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
   if constexpr (PTTS_ABLATE & 128) return;  // ablation 128 (timing only): empty kernels = launch + boundary cost
+  STAMP(0);
   constexpr bool Q8 = WF == 1;   // int8 weights, fp32 activations, fp32 MFMA
   constexpr bool SPL = WF == 3;  // split bf16 (hi + lo images, three bf16 MFMAs per block): see GemmArgs::wfmt
   constexpr bool B16 = WF == 2 || SPL;  // bf16 weights, activations rounded to bf16 in registers, v_mfma_f32_16x16x32_bf16
@@ -637,6 +652,7 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
   const std::integral_constant<int, U> cU{};
   const std::integral_constant<int, 1> c1{};
   const int nfull = (k1 - k0) / U;
+  STAMP(1);
   // chunk c of this wave covers k-fragments kfc(c) .. kfc(c) + U - 1; rotated by the column block for Linear layers
   const int rot = (a.krot && a.ntaps == 1 && nfull > 1) ? (int)(bx % nfull) : 0;
   auto kfc = [&](int c) { int i = c + rot; if (i >= nfull) i -= nfull; return k0 + i * U; };
@@ -684,6 +700,7 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
     compute_chunk(c1, kf, w1, x1);
   }
 
+  STAMP(2);
   f32x4 accs[TN][TM];
 #pragma unroll
   for (int i = 0; i < TN; ++i)
@@ -731,6 +748,7 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
       }
     }
     __syncthreads();
+    STAMP(3);
     if constexpr (PRE == PRE_LNFOLD) {
       const float invK = 1.0f / (float)(a.KF * 16);
 #pragma unroll
@@ -769,6 +787,7 @@ __global__ __launch_bounds__(64 * WK * WN * WM) void gemm_kernel(GemmArgs a) {
       for (int j = 0; j < TM; ++j)
         if (nt0 + i < a.NT && mt0 + j < a.MT) gemm_epilogue(a, ln_fix(accs[i][j], nt0 + i, j, nullptr), nt0 + i, mt0 + j, lane, par);
   }
+  STAMP(4);
   (void)NW;
 }
 
