@@ -90,6 +90,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the cpu_baseline leg")
     ap.add_argument("--latency-trials", type=int, default=200)
     ap.add_argument("--no-api", action="store_true", help="skip the API-level batch throughput (api_batch)")
+    ap.add_argument("--voices", choices=("distinct", "one"), default="distinct",
+                    help="distinct: every utterance of the batch has its own voice state (SURVEY 8d: conditioning f32[B,126,1024]; "
+                         "the headline); one: all clone ONE resident voice state, whose keys they then share (`one_voice` object)")
     ap.add_argument("--quick", action="store_true", help="A/B runs: only the timed region (no cpu baseline, latency, API, kernel profile)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="lower bound of the timed region's wall time")
     ap.add_argument("--min-utterances", type=int, default=3)
@@ -142,13 +145,15 @@ class Job:
         cfg = eng.cfg
         dev = eng.device
         g = torch.Generator().manual_seed(1 + seed)
-        voice = (torch.randn(1, args.voice_len, eng.D, generator=g) * 0.1).to(dev)
+        nv = B if getattr(args, "voices", "one") == "distinct" else 1
+        voice = (torch.randn(nv, args.voice_len, eng.D, generator=g) * 0.1).to(dev)
         g2 = torch.Generator().manual_seed(2 + seed)
         self.tokens = torch.randint(0, cfg.flow_lm.lookup_table.n_bins, (B, args.text_len), generator=g2).to(dev)
         cap = args.voice_len + args.text_len + args.frames + 1
-        # voice state is computed once and reused by every utterance (predefined voices are pre-baked KV
-        # files in the reference: tts_model.py:853-869)
-        self.voice = eng.new_lm_state(1, cap)
+        # voice states are computed once and cloned by every utterance (predefined voices are pre-baked KV files in the
+        # reference: tts_model.py:853-869).  distinct: one per row of the batch; one: a single state every row clones - the
+        # clones then borrow its first voice_len & ~15 keys instead of copying them (KvPrefix)
+        self.voice = eng.new_lm_state(nv, cap)
         eng.lm_prefill(self.voice, voice)
         self.st = eng.new_lm_state(B, cap)
         self.ms = eng.new_mimi_state(B)
@@ -250,6 +255,61 @@ def first_chunk_latency(eng, args, job1):
                 measured_through="TTSModel.generate_audio_stream()", trials=args.latency_trials,
                 engine_level_first_chunk_ms_p50=float(np.percentile(eng_ms, 50)),
                 b1_ms_per_step=per_step_ms, b1_xrt=FRAME_S * 1e3 / per_step_ms)
+
+
+def one_voice_throughput(eng, args, n_utt, seed, table_id, profile):
+    """The same utterance jobs with every row cloned from ONE resident voice state (64 requests against one voice, as
+    `api_batch` and a server with a handful of predefined voices run them): the clones borrow the voice's first
+    voice_len & ~15 keys (KvPrefix) and the decode attention scores them as MFMA tiles shared by 4 rows
+    (attn_cascade_kernel).  Same arithmetic to fp32 rounding (tests/test_gpu_prefix.py, test_gpu_parity_r3.py); reported
+    BESIDE the headline, whose rows have distinct voices as SURVEY 8d specifies."""
+    import numpy as np
+    import torch
+
+    a = argparse.Namespace(**vars(args))
+    a.voices = "one"
+    job = Job(eng, args.batch, a, seed=seed)
+    job.run_utterance()
+    job.sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_utt + 1)]
+    eng.sync()
+    torch.cuda.synchronize()
+    job.contexts = []
+    t0 = time.perf_counter()
+    marks[0].record(job.pipe.s2)
+    for u in range(n_utt):
+        job.run_utterance()
+        marks[u + 1].record(job.pipe.s2)
+    job.sync()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if job.st.error():
+        raise RuntimeError("a cooperative FlowLM kernel timed out in the one-voice leg")
+    utt_ms = [marks[u].elapsed_time(marks[u + 1]) for u in range(n_utt)]
+    rates = [args.batch * args.frames * FRAME_S / (m * 1e-3) for m in utt_ms]
+    pre = args.voice_len & ~15
+    out = dict(value=float(np.median(rates)), unit="audio-seconds/sec", ms_per_step=wall * 1e3 / (n_utt * args.frames),
+               utterances_timed=n_utt, utterance_ms=[round(m, 3) for m in utt_ms], shared_prefix_keys=pre,
+               options=dict(share_prefix=os.environ.get("PTTS_SHARE_PREFIX", "1"), prefix_cascade=os.environ.get("PTTS_CASCADE", "1")),
+               note="all rows clone ONE voice state and share its keys; the headline `value` is measured with a distinct voice per row")
+    if profile:
+        rows, per_kernel, nst, pctx = kernel_profile(eng, job)
+        for k, v in per_kernel.items():
+            if k.startswith(("attn_cascade", "attn_decode")):
+                t_ = eng.cfg.flow_lm.transformer
+                avg_s = v["total_ms"] / v["count"] * 1e-3
+                uniq = 2 * 4 * 64 * t_.num_heads * (pre + args.batch * (pctx - pre)) + 8.0 * args.batch * t_.num_heads * 64
+                # `achieved` on SURVEY 8d's per-sequence figure (what the reference's algorithm reads), `achieved_unique` with the
+                # shared keys counted once (what has to come from HBM); traffic = the committed PMC pass for this label or null
+                out["attention"] = dict(kernel=k, context_keys=pctx, avg_us=avg_s * 1e6, launches=v["count"],
+                                        algorithmic_bytes_per_launch=v["bytes"] / v["count"],
+                                        achieved_GBs=v["bytes"] / v["count"] / avg_s / 1e9,
+                                        frac=v["bytes"] / v["count"] / avg_s / 1e9 / HBM_PEAK_GBS,
+                                        unique_bytes_per_launch=uniq, achieved_unique_GBs=uniq / avg_s / 1e9,
+                                        frac_unique=uniq / avg_s / 1e9 / HBM_PEAK_GBS, traffic=pmc_traffic(k, table_id),
+                                        rocprof_pipelined_avg_us=rocprof_avg_us("attn_cascade_kernel"))
+        out["kernel_sum_ms_per_step"] = sum(r["total_ms"] for r in rows) / nst
+    return out, job
 
 
 def api_batch_throughput(eng, args, voice_lm_state):
@@ -393,10 +453,10 @@ def roofline_of(rows, table_id):
     common = dict(kernel=name, site=site, traffic=pmc_traffic(name, table_id), avg_us=avg_s * 1e6, launches=k["count"],
                   algorithmic_bytes_per_launch=k["bytes"] / k["count"], flops_per_launch=k["flops"] / k["count"],
                   timing="HIP events around each launch on its own stream (eager steps at mid-utterance context)")
-    if name.startswith("attn_decode"):
+    if name.startswith(("attn_decode", "attn_cascade")):
         # cross-check against the committed rocprofv3 summary: its average is over the whole PIPELINED run (codec stream
         # co-running, contexts up to 283 keys), so it is slower than the isolated eager launch timed here
-        common["rocprof_pipelined_avg_us"] = rocprof_avg_us("attn_decode2_kernel")
+        common["rocprof_pipelined_avg_us"] = rocprof_avg_us("attn_cascade_kernel" if name.startswith("attn_cascade") else "attn_decode2_kernel")
         common["rocprof_file"] = "profiles/" + STATS_FILE
     if tfs / MFMA_F32_PEAK_TF > gbs / HBM_PEAK_GBS:
         return dict(bound="mfma", achieved=tfs, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=tfs / MFMA_F32_PEAK_TF, **common)
@@ -640,7 +700,8 @@ def main():
                                 + (["fp8 e4m3 SEANet convs + bf16 Mimi transformer, f32 accumulate"] if args.codec_fp8 else [])) or "f32",
             "data": "synthetic (seeded weights, voice KV, token ids; fixed-length utterances, EOS stop disabled)",
             "config": {
-                "workload": f"{args.config}: batch {args.batch} concurrent utterances/GPU, voice KV {args.voice_len} + "
+                "workload": f"{args.config}: batch {args.batch} concurrent utterances/GPU, "
+                            f"{'a distinct voice per utterance' if args.voices == 'distinct' else 'one voice for all utterances'}, voice KV {args.voice_len} + "
                             f"text {args.text_len} tokens, {args.frames} frames (10 s) each, temp {args.temp}, "
                             f"lsd_decode_steps 1; per utterance: state clone + text prefill + FlowLM step + Mimi "
                             f"decode per frame, hipGraph per FlowLM step and per codec frame on two streams (step t+1 "
@@ -672,6 +733,10 @@ def main():
             "mfma_frac": flops_step / (MFMA_F32_PEAK_TF * 1e12) / step_s,
             "mean_context": ctx,
         }
+        if args.voices == "one" and os.environ.get("PTTS_SHARE_PREFIX", "1") != "0":  # the clones borrow the voice's first keys
+            pre = args.voice_len & ~15
+            out["step_roofline"]["shared_prefix_keys"] = pre
+            out["step_roofline"]["unique_bytes_per_step"] = bytes_step - (args.batch - 1) * 8 * L * pre * 1024
         if not args.no_profile:
             rows, per_kernel, nst, pctx = kernel_profile(eng, job)
             tid = out["tune_table_id"]
@@ -697,8 +762,15 @@ def main():
             job1 = Job(eng, 1, a1, seed=7)
             out["latency_b1"] = first_chunk_latency(eng, a1, job1)
             job1 = None
+        job_one = None
+        if world == 1 and args.voices == "distinct" and args.batch >= 16 and not args.quick:
+            out["one_voice"], job_one = one_voice_throughput(eng, args, n_utt, rank, out["tune_table_id"], not args.no_profile)
         if not args.no_api and world == 1 and args.preset in ("headline", "b1") and args.config != "24l" and args.batch > 1:
-            out["api_batch"] = api_batch_throughput(eng, args, job.voice)
+            if job_one is None:
+                a1v = argparse.Namespace(**vars(args))
+                a1v.voices = "one"
+                job_one = Job(eng, args.batch, a1v, seed=rank)
+            out["api_batch"] = api_batch_throughput(eng, args, job_one.voice)
             out["api_batch"]["engine_level_xrt"] = out["value"]
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args, cfg, W)

@@ -116,7 +116,9 @@ int ptts_lm_state_import(ptts_lm_state *s, int32_t layer, const float *d_cache, 
                          int32_t t, void *stream);
 int ptts_lm_state_export(ptts_lm_state *s, int32_t layer, float *d_cache, int32_t t, void *stream);
 /* dst <- src (replaces copy.deepcopy(model_state), tts_model.py:637-638); src batch 1 broadcasts.
- * The clone starts a new generation: its pending input latent is BOS (tts_model.py:748-753). */
+ * The clone starts a new generation: its pending input latent is BOS (tts_model.py:748-753).
+ * With "share_prefix" (default) a clone of a one-sequence state borrows its leading keys instead of copying them: see
+ * ptts_set_option.  These calls, destroy, reset, import and set_row_active serialise on the engine's mutex. */
 int ptts_lm_state_copy(ptts_lm_state *dst, const ptts_lm_state *src, void *stream);
 /* row `row` of dst <- the single sequence of src (batch 1): assembles a batch from utterances prefilled one by
  * one with different prompt lengths; every kernel reads per-row offsets, so rows need not be in sync (the
@@ -229,6 +231,20 @@ int ptts_tune_import(ptts_engine *e, const char *text);
  *   "flow_max_cus"  [PTTS_FLOW_MAX_CUS, 128] resident workgroups of the cooperative flow launch (8..CUs of the device): at most the number
  *                                           of CUs its stream may use (a CU-masked FlowLM stream needs it lowered; fewer is
  *                                           slower in the shared pipeline too: 128 -> 0.852, 64 -> 0.904, 32 -> 1.010 ms per step)
+ *   "share_prefix"  [PTTS_SHARE_PREFIX, 1]  1 = ptts_lm_state_copy / _copy_row(_from) from a ONE-sequence state (a voice state) do
+ *                                           not copy its first T & ~15 keys / values: the clone's rows BORROW them (the
+ *                                           attention kernels read those key tiles from the owner's cache), so the
+ *                                           utterances of one voice fetch them through L2 once instead of once per row, and a
+ *                                           clone copies < 16 positions.  Bitwise the same results as full copies.  While
+ *                                           lent, the owner refuses ptts_lm_state_reset / _import / being a copy
+ *                                           destination (-1); it may be prefilled further (appends only) and destroyed (its
+ *                                           memory is released when the last borrower is destroyed, re-cloned or reset).
+ *                                           Export materialises the borrowed positions.
+ *   "prefix_cascade" [PTTS_CASCADE, 1]      decode steps of >= 16 sequences: 1 = the scores against a prefix shared by 4
+ *                                           neighbouring rows are MFMA tiles computed once for the 4 (attn_cascade_kernel),
+ *                                           their private keys per row, merged in LDS; 0 = every row on its own.  Equal to
+ *                                           fp32 summation order, not bitwise; a row's bits then depend on whether its 4-row
+ *                                           group shares a prefix (a row next to other voices takes the per-row path)
  * Applies to steps enqueued / graphs captured after the call.  Returns -1 for an unknown key. */
 int ptts_set_option(ptts_engine *e, const char *key, int32_t value);
 /* 1 after a cooperative kernel of this state gave up waiting for a peer workgroup since the last call (the outputs of

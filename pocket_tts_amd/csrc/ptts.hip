@@ -145,6 +145,8 @@ struct ptts_engine {
   int opt_codec_lds_target = 56 * 1024;  // see lds_pad()
   int opt_fuse_res = 1;  // SEANet residual blocks of stages 2 and 3 as one launch each (gemm_lds_kernel<.., NT2>)
   int opt_flow_max_cus = 128;  // resident workgroups of the single-launch flow MLP (<= the CUs its stream may use)
+  int opt_share_prefix = 1;    // clones of a batch-1 state share its keys / values (KvPrefix) instead of copying them
+  int opt_cascade = 423;       // decode attention of such clones: 10 R + PW of attn_cascade_kernel (0: every sequence on its own)
   int n_cus = 256;             // hipDeviceProp_t::multiProcessorCount of `device` (cooperative grids never exceed it)
   std::recursive_mutex mu;  // entry points that enqueue work or touch tuner / profiler / LSD tables hold it
   int quant_flags = 0;
@@ -171,6 +173,14 @@ struct ptts_lm_state {
   unsigned long long *fflags = nullptr;
   int *ferr = nullptr;
   int flow_steps = 0, flow_rt = 1, flow_ng = 1;
+  // shared prefixes (KvPrefix): device table read by the attention kernels, its host mirror, and who owns each row's prefix.
+  // An owner with borrowers is not freed by ptts_lm_state_destroy until the last borrower lets go (`zombie`).
+  KvPrefix *d_pre = nullptr;
+  std::vector<KvPrefix> h_pre;
+  std::vector<ptts_lm_state *> pre_owner;
+  int n_pre = 0;        // rows of this state that have a prefix
+  int borrowers = 0;    // rows of OTHER states whose prefix is this state's cache
+  bool zombie = false;
   int n_graphs = 0;   // captured graphs that hold this state's buffer pointers (ensure_flow must not re-allocate under them)
   int coop_wgs = 0;   // workgroups of the cooperative launch of the last enqueued step (0: per-layer launches)
   // single-launch transformer stack (lm_cluster_kernel): exchange slots + flags, allocated on first use
@@ -833,6 +843,11 @@ static int attn_splits(int base, int max_tiles) {
   int s = std::max(1, cdiv(attn_wave_target(), std::max(1, base * nw)));
   return std::max(1, std::min(s, tiles));
 }
+// attn_cascade_kernel<R, PW, D, NS> shapes selectable with "prefix_cascade" / PTTS_CASCADE (default <4, 2, 3, 1>: measured in
+// profiles/r03_experiments.txt; more waves per workgroup or deeper register rings lose beside the codec stream)
+#define CASC_SHAPES \
+  CASC(442, 4, 4, 2, 2) CASC(422, 4, 2, 2, 2) CASC(222, 2, 2, 2, 2) CASC(443, 4, 4, 3, 1) CASC(413, 4, 1, 3, 1) CASC(424, 4, 2, 4, 1) \
+  CASC(823, 8, 2, 3, 1) CASC(213, 2, 1, 3, 1) CASC(42, 4, 2, 2, 1) CASC(44, 4, 4, 2, 1) CASC(84, 8, 4, 2, 1) CASC(22, 2, 2, 2, 1)
 static void launch_attn(hipStream_t st, const AttnArgs &at, int BH) {
   const dim3 grid(BH, at.QB, at.splits);
   const int nw = attn_nw(BH * at.QB);
@@ -856,6 +871,9 @@ struct TrCtx {
   float *h, *ao, *ff, *q, *part;
   float *Kc, *Vc;
   const int *offset;
+  const KvPrefix *pre = nullptr;  // shared voice prefixes of the sequences (FlowLM states) or null
+  int layer = 0;
+  int cascade = 0;                // decode steps: attn_cascade_kernel tile shape (10 R + PW) or 0
   const float *rope;  // [M][32][2]
   double kv_keys;  // sum over sequences of the keys attended (profiling only)
   const char *tag;
@@ -875,15 +893,39 @@ static void run_tr_layer(hipStream_t st, const TrLayer &T, const TrCtx &c) {
   AttnArgs at;
   at.Q = c.q; at.Kc = c.Kc; at.Vc = c.Vc; at.offset = c.offset; at.H = c.H; at.Tq = c.Tq; at.QB = c.QB;
   at.cap = c.cap; at.ring = c.ring; at.ctx = c.ctx; at.splits = c.splits; at.part = c.part; at.Y = c.ao; at.YF = DF; at.h16 = 0;
+  at.pre = c.pre; at.layer = c.layer;
   const int BH = (c.M / c.Tq) * c.H;
   SITE(s3.c_str());
   {
     // K and V rows of every attended key once per head + q in + o out
-    ProfScope ps(st, std::string(c.Tq == 1 ? "attn_decode" : "attn") + "@" + std::to_string((long)BH * c.QB * c.splits * 64 * (c.Tq == 1 ? decode_attn_waves(BH) : attn_nw(BH * c.QB))), c.kv_keys * c.H * 64 * 4 * 2 + 8.0 * c.M * c.D, 4.0 * c.kv_keys * c.H * 64 * std::min(c.Tq, 16));
+    const int nseq = BH / c.H;
+    at.nseq = nseq;
+    const bool casc = c.Tq == 1 && c.cascade && at.pre && c.splits == 1 && !c.ring && c.ctx <= 0 && nseq >= 16;
+    int casc_r = 4, casc_threads = 64 * 6;  // the default shape; others are A/B knobs
+    switch (c.cascade) {
+#define CASC(code, R, PW, D, NS) case code: casc_r = R; casc_threads = 64 * (R * NS + PW); break;
+      CASC_SHAPES
+#undef CASC
+    }
+    // bytes: SURVEY 8d's per-sequence figure (every sequence reads all of its keys), also for the cascade kernel, which
+    // fetches a shared prefix once per R sequences - bench.py reports the unique bytes next to it
+    ProfScope ps(st, casc ? "attn_cascade@" + std::to_string((long)cdiv(nseq, casc_r) * c.H * casc_threads)
+                          : std::string(c.Tq == 1 ? "attn_decode" : "attn") + "@" + std::to_string((long)BH * c.QB * c.splits * 64 * (c.Tq == 1 ? decode_attn_waves(BH) : attn_nw(BH * c.QB))),
+                 c.kv_keys * c.H * 64 * 4 * 2 + 8.0 * c.M * c.D, 4.0 * c.kv_keys * c.H * 64 * std::min(c.Tq, 16));
     if (c.Tq == 1) {
       // one query: vector ALU + wave reductions.  The keys of a (sequence, head) are split over the nw waves of ONE
       // workgroup and merged in LDS, so small batches reach ~1024 waves without partial buffers or a combine launch
       const int nw = decode_attn_waves(BH);
+      if (casc) {
+        // sequences cloned from one voice: prefix keys as MFMA tiles shared by R sequences, private keys per sequence,
+        // merged in LDS (attn_cascade_kernel).  Tile shape: tools/ab.sh env PTTS_CASCADE
+        switch (c.cascade) {
+#define CASC(code, R, PW, D, NS) case code: attn_cascade_kernel<R, PW, D, NS><<<cdiv(nseq, R) * c.H, 64 * (R * NS + PW), 0, st>>>(at); break;
+          CASC_SHAPES
+          default: attn_cascade_kernel<4, 2, 3, 1><<<cdiv(nseq, 4) * c.H, 64 * 6, 0, st>>>(at); break;
+#undef CASC
+        }
+      } else
       // the row-state kernel (no cross-row traffic in its loop).  Small batches: three register tiles (6.0 vs 7.2 us per
       // layer at batch 1, 221 keys).  >= 1024 (sequence, head) pairs: TWO register tiles - alone it streams at the rate of
       // the first kernel (attn_decode_kernel, 188 VGPRs, still selectable with PTTS_ATTN_V=1), but at ~110 registers per wave
@@ -954,6 +996,8 @@ static int init_engine_options(ptts_engine *e, int device) {
   if (const char *v = getenv("PTTS_LM_CLUSTER")) e->opt_lm_cluster = atoi(v) != 0;
   if (const char *v = getenv("PTTS_K_ROTATE")) e->opt_k_rotate = atoi(v) != 0;
   if (const char *v = getenv("PTTS_FUSE_RES")) e->opt_fuse_res = atoi(v) != 0;
+  if (const char *v = getenv("PTTS_SHARE_PREFIX")) e->opt_share_prefix = atoi(v) != 0;
+  if (const char *v = getenv("PTTS_CASCADE")) e->opt_cascade = atoi(v);
   if (const char *v = getenv("PTTS_FLOW_MAX_CUS")) e->opt_flow_max_cus = std::max(8, atoi(v));
   e->opt_flow_max_cus = std::min(e->opt_flow_max_cus, e->n_cus);  // a cooperative grid never exceeds the device
   if (const char *v = getenv("PTTS_CODEC_LDS_TARGET")) e->opt_codec_lds_target = std::max(0, std::min(atoi(v), 64 * 1024));
@@ -1450,6 +1494,9 @@ static int build_lm_state(ptts_engine *e, ptts_lm_state *s) {
   CHK(dallocT(nullptr, &s->kv, (size_t)c.num_layers * 2 * s->kv_plane()));
   CHK(dallocT(nullptr, &s->offset, B));
   s->h_off.assign(B, 0);
+  CHK(dalloc(nullptr, (void **)&s->d_pre, (size_t)B * sizeof(KvPrefix)));
+  s->h_pre.assign(B, KvPrefix{nullptr, 0, 0});
+  s->pre_owner.assign(B, nullptr);
   CHK(alloc_scratch(e, &s->dec, B, 1, c.d_model, c.num_heads, c.ff_dim, s->cap));
   const size_t rt = (size_t)s->MT * 256;
   const int FD = c.flow_dim;
@@ -1476,11 +1523,9 @@ static int build_lm_state(ptts_engine *e, ptts_lm_state *s) {
   return 0;
 }
 
-extern "C" void ptts_lm_state_destroy(ptts_lm_state *s) {
-  if (!s) return;
-  hipSetDevice(s->e->device);
-  hipDeviceSynchronize();
-  hipFree(s->kv); hipFree(s->offset);
+// ---- shared prefixes: bookkeeping (host side; the device table is updated by set_prefix_kernel on the caller's stream)
+static void lm_state_free(ptts_lm_state *s) {
+  hipFree(s->kv); hipFree(s->offset); hipFree(s->d_pre);
   free_scratch(&s->dec);
   if (s->pre.x) free_scratch(&s->pre);
   hipFree(s->xlat); hipFree(s->latfm); hipFree(s->c); hipFree(s->ce); hipFree(s->mod); hipFree(s->fx);
@@ -1488,9 +1533,52 @@ extern "C" void ptts_lm_state_destroy(ptts_lm_state *s) {
   hipFree(s->fexch); hipFree(s->fflags); hipFree(s->ferr); hipFree(s->lexch); hipFree(s->lflags);
   delete s;
 }
+static void prefix_release(ptts_lm_state *s, int row) {  // the row stops reading its owner's cache
+  ptts_lm_state *o = s->pre_owner[row];
+  if (!o) return;
+  s->pre_owner[row] = nullptr;
+  s->h_pre[row] = KvPrefix{nullptr, 0, 0};
+  s->n_pre -= 1;
+  o->borrowers -= 1;
+  if (o->zombie && o->borrowers == 0) {  // its destroy was deferred until now; the GPU may still be reading it
+    hipDeviceSynchronize();
+    lm_state_free(o);
+  }
+}
+static void prefix_borrow(ptts_lm_state *s, int row, ptts_lm_state *owner, int len) {
+  if (s->pre_owner[row] == owner && s->h_pre[row].len == len) return;
+  owner->borrowers += 1;  // before the release: re-borrowing from the same (zombie) owner must not free it in between
+  prefix_release(s, row);
+  s->pre_owner[row] = owner;
+  s->h_pre[row] = KvPrefix{owner->kv, owner->cap, len};
+  s->n_pre += 1;
+}
+// a state whose cache other states read as their prefix must not have it rewritten under them
+static int refuse_if_lent(const ptts_lm_state *s, const char *what) {
+  if (s->borrowers > 0) return fail(-1, std::string(what) + ": this state's cache is the shared prefix of " + std::to_string(s->borrowers) +
+                                           " sequence(s) cloned from it; destroy or re-clone them first");
+  return 0;
+}
+
+extern "C" void ptts_lm_state_destroy(ptts_lm_state *s) {
+  if (!s) return;
+  ENGINE_LOCK(s->e);  // the borrow counts of OTHER states (prefix owners) change here
+  hipSetDevice(s->e->device);
+  hipDeviceSynchronize();
+  for (int b = 0; b < (int)s->pre_owner.size(); ++b) prefix_release(s, b);  // (empty after a failed creation)
+  if (s->borrowers > 0) {  // clones still read this cache: the memory goes when the last of them lets go
+    s->zombie = true;
+    return;
+  }
+  lm_state_free(s);
+}
 
 extern "C" int ptts_lm_state_reset(ptts_lm_state *s, void *stream) {
   hipStream_t st = S(s->e, stream);
+  ENGINE_LOCK(s->e);
+  CHK(refuse_if_lent(s, "reset"));
+  for (int b = 0; b < s->B; ++b) prefix_release(s, b);
+  set_prefix_kernel<<<cdiv(s->B, 256), 256, 0, st>>>(s->d_pre, s->B, nullptr, 0, 0);
   set_int_kernel<<<cdiv(s->B, 256), 256, 0, st>>>(s->offset, s->B, 0);
   fill_kernel<<<cdiv(s->B * s->e->cfg.ldim, 256), 256, 0, st>>>(s->lat_prev, (long)s->B * s->e->cfg.ldim, NAN);
   std::fill(s->h_off.begin(), s->h_off.end(), 0);
@@ -1507,6 +1595,12 @@ extern "C" int ptts_lm_state_import(ptts_lm_state *s, int32_t layer, const float
   if (t > s->cap) return fail(-5, "import: t exceeds cache capacity");
   if (src_batch != 1 && src_batch != s->B) return fail(-1, "import: src_batch must be 1 or B");
   hipStream_t st = S(s->e, stream);
+  ENGINE_LOCK(s->e);
+  CHK(refuse_if_lent(s, "import"));
+  if (s->n_pre > 0) {  // the imported rows are complete copies
+    for (int b = 0; b < s->B; ++b) prefix_release(s, b);
+    set_prefix_kernel<<<cdiv(s->B, 256), 256, 0, st>>>(s->d_pre, s->B, nullptr, 0, 0);
+  }
   if (t > 0) {
     long total = 2L * s->B * t * c.num_heads * 16;
     kv_import_kernel<<<cdiv(total, 256), 256, 0, st>>>(d_cache, s->K(layer), s->V(layer), s->B, src_batch, t,
@@ -1524,41 +1618,83 @@ extern "C" int ptts_lm_state_export(ptts_lm_state *s, int32_t layer, float *d_ca
   if (t > s->cap) return fail(-5, "export: t exceeds cache capacity");
   hipStream_t st = S(s->e, stream);
   long total = 2L * s->B * t * c.num_heads * 16;
-  if (total) kv_export_kernel<<<cdiv(total, 256), 256, 0, st>>>(d_cache, s->K(layer), s->V(layer), s->B, t, c.num_heads, s->cap);
+  if (total) kv_export_kernel<<<cdiv(total, 256), 256, 0, st>>>(d_cache, s->K(layer), s->V(layer), s->B, t, c.num_heads, s->cap,
+                                                                 s->n_pre > 0 ? s->d_pre : nullptr, layer);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
+// KV rows of (src, src_row) -> (dst, row).  With "share_prefix" the destination row BORROWS the leading positions instead
+// of copying them: from src itself when src is a one-sequence state (a cached voice state: every clone of it reads the same
+// [0, T & ~15) keys, so the clones' attention fetches them once through L2 instead of once per row), or from the state
+// src's row already borrows from.  Only the private positions behind the prefix are copied.  Without the option a
+// borrowed prefix is materialised into dst.  Host table only; the caller updates dst->d_pre.
+static int kv_clone_row(ptts_lm_state *dst, int row, const ptts_lm_state *src, int src_row, int T, hipStream_t st) {
+  const ptts_config &c = dst->e->cfg;
+  const int planes = c.num_layers * 2, H = c.num_heads;
+  ptts_lm_state *owner = src->pre_owner[src_row];
+  int plen = owner ? src->h_pre[src_row].len : 0;
+  if (plen > T) plen = 0, owner = nullptr;  // cannot happen (offsets only grow past a prefix); a full copy is always right
+  bool share = dst->e->opt_share_prefix && !dst->e->opt_lm_cluster && dst != src;  // (the single-launch stack reads own caches only)
+  if (share && !owner && src->B == 1 && !src->zombie && T >= 16) owner = const_cast<ptts_lm_state *>(src), plen = T & ~15;
+  if (!owner || owner == dst) share = false;
+  int t0 = 0;
+  if (share) {
+    prefix_borrow(dst, row, owner, plen);
+    t0 = owner == src ? plen : src->h_pre[src_row].len;
+  } else {
+    prefix_release(dst, row);
+    if (src->pre_owner[src_row]) {  // materialise the part src only borrows
+      const ptts_lm_state *o = src->pre_owner[src_row];
+      t0 = src->h_pre[src_row].len;
+      const long total = (long)planes * H * t0 * 16;
+      kv_copy_row_kernel<<<cdiv(total, 256), 256, 0, st>>>(dst->kv, o->kv, planes, H, t0, o->cap, dst->cap, dst->B, row, o->B, 0, 0);
+    }
+  }
+  if (T > t0) {
+    const long total = (long)planes * H * (T - t0) * 16;
+    kv_copy_row_kernel<<<cdiv(total, 256), 256, 0, st>>>(dst->kv, src->kv, planes, H, T - t0, src->cap, dst->cap, dst->B, row, src->B, src_row, t0);
+  }
+  return 0;
+}
+static int upload_prefixes(ptts_lm_state *s, hipStream_t st) {
+  bool uniform = true;
+  for (int b = 1; b < s->B; ++b) uniform &= s->h_pre[b].kv == s->h_pre[0].kv && s->h_pre[b].len == s->h_pre[0].len && s->h_pre[b].cap == s->h_pre[0].cap;
+  if (uniform) {
+    set_prefix_kernel<<<cdiv(s->B, 256), 256, 0, st>>>(s->d_pre, s->B, s->h_pre[0].kv, s->h_pre[0].cap, s->h_pre[0].len);
+  } else {
+    HIPCHK(hipMemcpyAsync(s->d_pre, s->h_pre.data(), s->B * sizeof(KvPrefix), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));  // pageable host memory
+  }
+  return 0;
+}
+
 extern "C" int ptts_lm_state_copy(ptts_lm_state *dst, const ptts_lm_state *src, void *stream) {
+  if (!dst || !src) return fail(-1, "null state");
   if (dst->e != src->e) return fail(-1, "states belong to different engines");
   if (src->B != 1 && src->B != dst->B) return fail(-1, "copy: src batch must be 1 or equal");
+  if (dst == src) return 0;
   const ptts_config &c = dst->e->cfg;
   hipStream_t st = S(dst->e, stream);
+  ENGINE_LOCK(dst->e);
+  CHK(refuse_if_lent(dst, "copy"));
   const int T = *std::max_element(src->h_off.begin(), src->h_off.end());
   if (T > dst->cap) return fail(-5, "copy: destination capacity too small");
-  if (dst->cap == src->cap) {
+  const bool had_pre = dst->n_pre > 0;
+  const bool plain = src->n_pre == 0 && !(dst->e->opt_share_prefix && !dst->e->opt_lm_cluster && src->B == 1 && T >= 16);
+  if (plain && dst->cap == src->cap) {
+    for (int b = 0; b < dst->B; ++b) prefix_release(dst, b);
     long per_row = (long)c.num_heads * dst->cap * 64;
     long total = (long)c.num_layers * 2 * dst->B * (per_row / 4);
     kv_copy_kernel<<<cdiv(total, 256), 256, 0, st>>>(dst->kv, src->kv, per_row, dst->B, src->B, c.num_layers * 2);
-  } else if (src->B == 1) {
-    // different capacities, one source sequence (a cached voice state cloned into a generation state): one row-copy
-    // kernel per destination row instead of L x 2 x H memcpys
-    if (T)
-      for (int b = 0; b < dst->B; ++b) {
-        const long total = (long)c.num_layers * 2 * c.num_heads * T * 16;
-        kv_copy_row_kernel<<<cdiv(total, 256), 256, 0, st>>>(dst->kv, src->kv, c.num_layers * 2, c.num_heads, T, src->cap, dst->cap, dst->B, b);
-      }
   } else {
-    // different capacities: go plane by plane through the reference layout-free row copy
-    for (int pl = 0; pl < c.num_layers * 2; ++pl)
-      for (int b = 0; b < dst->B; ++b)
-        for (int h = 0; h < c.num_heads; ++h) {
-          const int sb = src->B == 1 ? 0 : b;
-          const float *sp = src->kv + (((size_t)pl * src->B + sb) * c.num_heads + h) * src->cap * 64;
-          float *dp = dst->kv + (((size_t)pl * dst->B + b) * c.num_heads + h) * dst->cap * 64;
-          if (T) HIPCHK(hipMemcpyAsync(dp, sp, (size_t)T * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
-        }
+    // row by row: one copy kernel per destination row for the positions it does not share
+    for (int b = 0; b < dst->B; ++b) {
+      const int sb = src->B == 1 ? 0 : b;
+      CHK(kv_clone_row(dst, b, src, sb, src->h_off[sb], st));
+    }
   }
+  if (had_pre || dst->n_pre > 0) CHK(upload_prefixes(dst, st));
   for (int b = 0; b < dst->B; ++b) dst->h_off[b] = src->h_off[src->B == 1 ? 0 : b];
   if (*std::min_element(dst->h_off.begin(), dst->h_off.end()) == T) {
     set_int_kernel<<<cdiv(dst->B, 256), 256, 0, st>>>(dst->offset, dst->B, T);
@@ -1582,15 +1718,19 @@ extern "C" int ptts_lm_state_copy_row_from(ptts_lm_state *dst, int32_t row, cons
   if (!dst || !src) return fail(-1, "null state");
   if (dst->e != src->e) return fail(-1, "states belong to different engines");
   if (src_row < 0 || src_row >= src->B || row < 0 || row >= dst->B) return fail(-1, "copy_row: row out of range");
+  if (dst == src) return fail(-1, "copy_row: source and destination are the same state");
   const ptts_config &c = dst->e->cfg;
   hipStream_t st = S(dst->e, stream);
   HIPCHK(hipSetDevice(dst->e->device));
+  ENGINE_LOCK(dst->e);
+  CHK(refuse_if_lent(dst, "copy_row"));
   const int T = src->h_off[src_row];
   if (T > dst->cap) return fail(-5, "copy_row: destination capacity too small");
-  if (T) {
-    const long total = (long)c.num_layers * 2 * c.num_heads * T * 16;
-    kv_copy_row_kernel<<<cdiv(total, 256), 256, 0, st>>>(dst->kv, src->kv, c.num_layers * 2, c.num_heads, T, src->cap, dst->cap, dst->B, row,
-                                                        src->B, src_row);
+  const bool had_pre = dst->pre_owner[row] != nullptr;
+  CHK(kv_clone_row(dst, row, src, src_row, T, st));
+  if (had_pre || dst->pre_owner[row]) {
+    const KvPrefix &p = dst->h_pre[row];
+    set_prefix_kernel<<<1, 64, 0, st>>>(dst->d_pre + row, 1, p.kv, p.cap, p.len);
   }
   dst->h_off[row] = T;
   dst->h_active[row] = 1;
@@ -1607,11 +1747,16 @@ extern "C" int ptts_lm_state_copy_row_from(ptts_lm_state *dst, int32_t row, cons
 extern "C" int ptts_lm_state_set_row_active(ptts_lm_state *s, int32_t row, int32_t active, void *stream) {
   if (!s || row < 0 || row >= s->B) return fail(-1, "set_row_active: row out of range");
   hipStream_t st = S(s->e, stream);
+  ENGINE_LOCK(s->e);
   s->h_active[row] = active ? 1 : 0;
   set_int_kernel<<<1, 64, 0, st>>>(s->active + row, 1, active ? 1 : 0);
   if (!active) {
     s->h_off[row] = 0;
     set_int_kernel<<<1, 64, 0, st>>>(s->offset + row, 1, 0);
+    if (s->pre_owner[row]) {  // a parked row reads key 0 of its own cache only
+      prefix_release(s, row);
+      set_prefix_kernel<<<1, 64, 0, st>>>(s->d_pre + row, 1, nullptr, 0, 0);
+    }
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -1762,6 +1907,7 @@ static constexpr int kLmMaxWGs = 256;  // resident workgroups of one launch (one
 static bool lm_cluster_ok(const ptts_engine *e, const ptts_lm_state *s) {
   if (!e->opt_lm_cluster || !e->lm_table) return false;
   if (e->cfg.d_model / 16 > std::min(kLmMaxWGs, e->n_cus)) return false;  // one cluster must be resident at once
+  if (s->n_pre > 0) return false;  // the single-launch stack reads its keys from the state's own cache only
   return (double)s->kv_plane() * 4.0 < 2.0e9;  // 32-bit buffer offsets into a K / V plane
 }
 static int ensure_lm_cluster(ptts_engine *e, ptts_lm_state *s, hipStream_t st) {
@@ -1864,6 +2010,7 @@ static void lm_layers(hipStream_t st, ptts_engine *e, ptts_lm_state *s, Scratch 
     t.x_in = sc.x; t.x = sc.x; t.x_out = sc.x; t.out_ds = 0; t.par = nullptr;
     t.h = sc.h; t.ao = sc.ao; t.ff = sc.ff; t.q = sc.q; t.part = sc.part;
     t.Kc = s->K(l); t.Vc = s->V(l); t.offset = s->offset; t.rope = sc.rope;
+    t.pre = s->d_pre; t.layer = l; t.cascade = e->opt_share_prefix ? e->opt_cascade : 0;
     t.kv_keys = 0;
     for (int b = 0; b < s->B; ++b) t.kv_keys += s->h_off[b] + Tq;
     t.tag = "lm";
@@ -2833,6 +2980,8 @@ extern "C" int ptts_set_option(ptts_engine *e, const char *key, int32_t value) {
   else if (k == "lm_cluster") e->opt_lm_cluster = value != 0;
   else if (k == "k_rotate") e->opt_k_rotate = value != 0;
   else if (k == "fuse_res") e->opt_fuse_res = value != 0;
+  else if (k == "share_prefix") e->opt_share_prefix = value != 0;
+  else if (k == "prefix_cascade") e->opt_cascade = value == 1 ? 423 : value;
   else if (k == "codec_lds_target") {
     if (value < 0 || value > 64 * 1024) return fail(-1, "codec_lds_target must be in [0, 65536]");
     e->opt_codec_lds_target = value;

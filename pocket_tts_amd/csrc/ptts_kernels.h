@@ -1456,6 +1456,18 @@ static __global__ void zero_row_fm_kernel(float *buf, int F, int row) {
   const int kf = i >> 4, g = (i >> 2) & 3, j4 = i & 3;
   buf[(((size_t)(row >> 4) * F + kf) * 64 + 16 * g + (row & 15)) * 4 + j4] = 0.f;
 }
+// A sequence whose first `len` positions (a multiple of 16) are the keys / values of ANOTHER state's cache: the voice prefix
+// that every utterance cloned from one voice state shares (reference: the per-chunk deepcopy of the voice state,
+// tts_model.py:637-638, gives every generation its own copy of the same bytes).  `kv` = base of the owner's cache
+// [L][2][1][H][cap][64]; the sequence's own cache holds positions >= len at their absolute slots.
+struct KvPrefix {
+  const float *kv;
+  int cap, len;
+};
+static __global__ void set_prefix_kernel(KvPrefix *p, int n, const float *kv, int cap, int len) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = KvPrefix{kv, cap, len};
+}
 static __global__ void set_int_kernel(int *p, int n, int v) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -1505,14 +1517,26 @@ static __global__ void timestep_embed_kernel(const float *freqs, float t, float 
 // ---------------------------------------------------------------------------------------------
 struct AttnArgs {
   const float *Q, *Kc, *Vc;
+  const KvPrefix *pre = nullptr;  // per-sequence shared prefixes (linear caches only) or null
+  int layer = 0;                  // layer index into a prefix owner's cache
   const int *offset;
   int H, Tq, QB, cap, ring, ctx, splits;
   float *part;  // [BH*QB][splits][16][64 + 2 (pad to 80)]
   float *Y;
   int YF;
   int h16;  // output as bf16 FMH (YF = 32-column blocks) instead of fp32 FM
+  int nseq = 0;  // sequences in the launch (attn_cascade_kernel: its groups of R may overhang)
 };
 #define ATT_PSTRIDE 80
+// key tiles [0, ptl) of (sequence b, head h) come from Kp / Vp (the prefix owner's cache), the rest from the sequence's own
+__device__ __forceinline__ int attn_prefix(const AttnArgs &a, int b, int h, const float *&Kp, const float *&Vp) {
+  if (!a.pre) return 0;
+  const KvPrefix p = a.pre[b];
+  if (p.len <= 0) return 0;
+  Kp = p.kv + ((size_t)(2 * a.layer) * a.H + h) * p.cap * 64;
+  Vp = p.kv + ((size_t)(2 * a.layer + 1) * a.H + h) * p.cap * 64;
+  return p.len >> 4;
+}
 
 // Cross-row all-reduce over the four 16-lane rows of a wave on the vector ALU (gfx950 v_permlane16_swap /
 // v_permlane32_swap): lanes c, c + 16, c + 32, c + 48 end up with the max / sum of their four values.  The ds_bpermute
@@ -1594,13 +1618,16 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) o[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float m_run = NEG_BIG, l_run = 0.f;
-  const float *Kb = a.Kc + (size_t)bh * a.cap * 64;
-  const float *Vb = a.Vc + (size_t)bh * a.cap * 64;
+  const float *Kown = a.Kc + (size_t)bh * a.cap * 64;
+  const float *Vown = a.Vc + (size_t)bh * a.cap * 64;
+  const float *Kpre = Kown, *Vpre = Vown;
+  const int ptl = attn_prefix(a, b, h, Kpre, Vpre);  // shared-prefix tiles: a pointer select, ONE load site
   const int pq = q0 + c;
 
   auto load_tile = [&](int tile, f32x4 *kk, f32x4 *vv) {
     const int p0 = tile * 16;
     const int slot0 = a.ring ? (p0 % a.ring) : p0;
+    const float *Kb = tile < ptl ? Kpre : Kown, *Vb = tile < ptl ? Vpre : Vown;
 #pragma unroll
     // each (sequence, head) streams its keys and values once per launch: non-temporal loads (see attn_decode_kernel)
     for (int df = 0; df < 4; ++df)
@@ -1750,14 +1777,17 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(AttnArgs a) {
 #pragma unroll
   for (int df = 0; df < 4; ++df)
     qv[df] = *(const f32x4 *)(a.Q + ((((size_t)bh * a.QB) * 4 + df) * 64 + 16 * g) * 4) * 0.125f;
-  const float *Kb = a.Kc + (size_t)bh * a.cap * 64;
-  const float *Vb = a.Vc + (size_t)bh * a.cap * 64;
+  const float *Kown = a.Kc + (size_t)bh * a.cap * 64;
+  const float *Vown = a.Vc + (size_t)bh * a.cap * 64;
+  const float *Kpre = Kown, *Vpre = Vown;
+  const int ptl = attn_prefix(a, b, h, Kpre, Vpre);
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
   float m_run = NEG_BIG, l_run = 0.f;
 
   auto load_tile = [&](int tile, f32x4 *kk, f32x4 *vv) {
     const int p0 = tile * 16;
     const int slot0 = a.ring ? (p0 % a.ring) : p0;
+    const float *Kb = tile < ptl ? Kpre : Kown, *Vb = tile < ptl ? Vpre : Vown;
 #pragma unroll
     // the cache is streamed once per step: non-temporal loads (profiles/r01_fetch_size_calibration.csv: a 1 GiB
     // stream reads at 7.4 TB/s with nt loads, 4.8 TB/s with plain ones)
@@ -1892,14 +1922,19 @@ __global__ __launch_bounds__(64 * NW) void attn_decode2_kernel(AttnArgs a) {
 
   // q[4 cc .. 4 cc + 3] / sqrt(64): row 0 of the query block, fragment cc / 4, k-group cc % 4
   const f32x4 q = *(const f32x4 *)(a.Q + ((((size_t)bh * a.QB) * 4 + (cc >> 2)) * 64 + 16 * (cc & 3)) * 4) * 0.125f;
-  const float *Kb = a.Kc + (size_t)bh * a.cap * 64 + lane * 4;
-  const float *Vb = a.Vc + (size_t)bh * a.cap * 64 + lane * 4;
+  const float *Kown = a.Kc + (size_t)bh * a.cap * 64;
+  const float *Vown = a.Vc + (size_t)bh * a.cap * 64;
+  const float *Kpre = Kown, *Vpre = Vown;
+  // tiles of a shared voice prefix come from its owner's cache: 64 utterances of one voice then stream those keys from L2
+  // (all sequences of a head sit on one XCD: bh % 8 == h % 8 for 16 heads) instead of 64 private copies from HBM
+  const int ptl = attn_prefix(a, b, h, Kpre, Vpre);
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
   float m_run = NEG_BIG, l_run = 0.f;
 
   auto load_tile = [&](int tile, KvTile &t) {
     const int p0 = tile * 16;
-    const size_t base = (size_t)(a.ring ? (p0 % a.ring) : p0) * 64;
+    const size_t base = (size_t)(a.ring ? (p0 % a.ring) : p0) * 64 + lane * 4;
+    const float *Kb = tile < ptl ? Kpre : Kown, *Vb = tile < ptl ? Vpre : Vown;  // uniform select, one load site
 #pragma unroll
     for (int i = 0; i < 4; ++i) t.k[i] = __builtin_nontemporal_load((const f32x4 *)(Kb + base + 256 * i));
 #pragma unroll
@@ -1998,6 +2033,222 @@ __global__ __launch_bounds__(64 * NW) void attn_decode2_kernel(AttnArgs a) {
   }
 }
 
+// Decode-step attention for sequences that share a prefix ("cascade"): B utterances cloned from one voice state attend the
+// SAME first `len` keys (KvPrefix), so the scores against those keys are a matrix product Q[rows] x K_prefix^T, not B
+// separate matrix-vector products.  One workgroup = R consecutive sequences of one head:
+//   * waves 0 .. R-1   ("suffix"): attn_decode2_kernel's row-state stream over the sequence's PRIVATE keys [len, pos];
+//   * waves R .. R+PW-1 ("prefix"): attn_kernel's MFMA tiles over a 1/PW share of the prefix keys with the R queries in
+//     the B operand's columns (R of 16 columns used: the tile costs 32 MFMAs per 16 keys whatever R is), so the prefix is
+//     fetched once per R sequences, with plain (cacheable) loads - the other workgroups of the head read it from L2;
+//   * the PW partial (m, l, o) of a row meet its suffix state in LDS; the suffix wave writes the output.  No partial
+//     buffers in memory, no combine launch.
+// A sequence whose prefix differs from that of the group's first sequence (other voice, no prefix, parked row) is
+// handled entirely by its suffix wave, prefix tiles through the pointer select of the kernels above.  Linear caches,
+// no window (FlowLM).  Summation order differs from attn_decode2_kernel's: results equal to fp32 rounding, not bitwise.
+template <int R, int PW, int D, int NS = 1>
+__global__ __launch_bounds__(64 * (R * NS + PW)) void attn_cascade_kernel(AttnArgs a) {
+  if constexpr (PTTS_ABLATE & 128) return;
+  const int bg = blockIdx.x / a.H, h = blockIdx.x - bg * a.H;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b0 = bg * R;
+  const KvPrefix p0 = a.pre[b0];
+  const int ptl0 = p0.len >> 4;  // the group's shared tiles (0: nothing shared)
+  constexpr int NP = PW + NS - 1;  // partials a sequence's first suffix wave merges: PW prefix shares, NS - 1 suffix shares
+  __shared__ f32x4 so[NP][R][16];
+  __shared__ float sm[NP][R], sl[NP][R];
+
+  if (wave >= R * NS) {
+    // ---- prefix wave: 16-key MFMA tiles, queries of the R sequences in columns c % R
+    const int pw = wave - R * NS, c = lane & 15, g = lane >> 4;
+    const int perw = (ptl0 + PW - 1) / PW;
+    const int ts = pw * perw, te = min(ptl0, ts + perw);
+    const int bq = min(b0 + (c & (R - 1)), a.nseq - 1);
+    f32x4 qf[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df)  // row 0 of sequence bq's query block: Q[16 df + 4 g + j]
+      qf[df] = *(const f32x4 *)(a.Q + (((((size_t)bq * a.H + h) * a.QB) * 4 + df) * 64 + 16 * g) * 4) * 0.125f;
+    f32x4 o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = NEG_BIG, l_run = 0.f;
+    const float *Kp = p0.kv + ((size_t)(2 * a.layer) * a.H + h) * p0.cap * 64;
+    const float *Vp = p0.kv + ((size_t)(2 * a.layer + 1) * a.H + h) * p0.cap * 64;
+    auto load_tile = [&](int tile, f32x4 *kk, f32x4 *vv) {
+      const int p = tile * 16;
+#pragma unroll
+      for (int df = 0; df < 4; ++df) kk[df] = *(const f32x4 *)(Kp + (size_t)(p + c) * 64 + 16 * df + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vv[r] = *(const f32x4 *)(Vp + (size_t)(p + 4 * g + r) * 64 + 4 * c);
+    };
+    auto process = [&](const f32x4 *kf4, const f32x4 *vf4) {  // every key of a prefix tile is visible to every query
+      f32x4 sp4[4];
+#pragma unroll
+      for (int df = 0; df < 4; ++df) sp4[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cidx = 0; cidx < 4; ++cidx)
+#pragma unroll
+        for (int df = 0; df < 4; ++df)
+          sp4[df] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf4[df][cidx], qf[df][cidx], sp4[df], 0, 0, 0);
+      const f32x4 s = (sp4[0] + sp4[1]) + (sp4[2] + sp4[3]);  // s[r] = score(key 4 g + r, query c)
+      const float mx = xrow_max(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = expf(m_run - m_new);
+      f32x4 p;
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p[r] = expf(s[r] - m_new);
+        ps += p[r];
+      }
+      ps = xrow_sum(ps);
+      l_run = l_run * alpha + ps;
+      m_run = m_new;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf4[r].x, p[r], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf4[r].y, p[r], o[1], 0, 0, 0);
+        o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf4[r].z, p[r], o[2], 0, 0, 0);
+        o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf4[r].w, p[r], o[3], 0, 0, 0);
+      }
+    };
+    f32x4 kt[D][4], vt[D][4];
+    if (ts < te) {
+      const int tl = te - 1;
+#pragma unroll
+      for (int j = 0; j < D - 1; ++j) load_tile(min(ts + j, tl), kt[j], vt[j]);
+      int tile = ts;
+      for (; tile + D <= te; tile += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          load_tile(min(tile + j + D - 1, tl), kt[(j + D - 1) % D], vt[(j + D - 1) % D]);
+          process(kt[j], vt[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < D - 1; ++j)
+        if (tile + j < te) process(kt[j], vt[j]);
+    }
+    if (c < R) {  // lane (c, g) holds O[query c][16 g + 4 rr + j] in o[j][rr]
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) so[pw][c][4 * g + rr] = (f32x4){o[0][rr], o[1][rr], o[2][rr], o[3][rr]};
+      if (g == 0) { sm[pw][c] = m_run; sl[pw][c] = l_run; }
+    }
+    __syncthreads();
+    return;
+  }
+
+  // ---- suffix wave: one sequence, its private keys (or all of them when it does not share the group's prefix)
+  const int cc = lane & 15, rw = lane >> 4;
+  const int row = wave / NS, part = wave - row * NS;  // NS waves split a sequence's private tiles
+  const int b = b0 + row;
+  const bool live = b < a.nseq;
+  const int bs = live ? b : a.nseq - 1;
+  const KvPrefix pb = a.pre[bs];
+  const bool casc = live && ptl0 > 0 && pb.kv == p0.kv && pb.len == p0.len && pb.cap == p0.cap;
+  const int pq = a.offset[bs];
+  const int tile_hi = (pq + 16) >> 4;
+  const int bh = bs * a.H + h;
+  const f32x4 q = *(const f32x4 *)(a.Q + ((((size_t)bh * a.QB) * 4 + (cc >> 2)) * 64 + 16 * (cc & 3)) * 4) * 0.125f;
+  const float *Kown = a.Kc + (size_t)bh * a.cap * 64;
+  const float *Vown = a.Vc + (size_t)bh * a.cap * 64;
+  const float *Kpre = Kown, *Vpre = Vown;
+  const int ptl = attn_prefix(a, bs, h, Kpre, Vpre);
+  const int gs = casc ? ptl0 : 0, ge = live ? tile_hi : 0;
+  const int perw = (max(ge - gs, 0) + NS - 1) / NS;
+  const int ts = gs + part * perw, te = min(ge, ts + perw);
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  float m_run = NEG_BIG, l_run = 0.f;
+  auto load_tile = [&](int tile, KvTile &t) {
+    const size_t base = (size_t)tile * 16 * 64 + lane * 4;
+    const float *Kb = tile < ptl ? Kpre : Kown, *Vb = tile < ptl ? Vpre : Vown;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.k[i] = __builtin_nontemporal_load((const f32x4 *)(Kb + base + 256 * i));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.v[i] = __builtin_nontemporal_load((const f32x4 *)(Vb + base + 256 * i));
+  };
+  auto process = [&](int tile, const KvTile &t) {
+    float s[4];
+    bool ok[4];
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s[i] = row16_sum((t.k[i].x * q.x + t.k[i].y * q.y) + (t.k[i].z * q.z + t.k[i].w * q.w));
+      ok[i] = tile * 16 + 4 * i + rw <= pq;
+      mx = ok[i] ? fmaxf(mx, s[i]) : mx;
+    }
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = expf(m_run - m_new);
+    o *= alpha;
+    float ps = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float p = ok[i] ? expf(s[i] - m_new) : 0.f;
+      ps += p;
+      o += t.v[i] * p;
+    }
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+  };
+  KvTile t[D];
+  if (ts < te) {
+    const int tl = te - 1;
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) load_tile(min(ts + j, tl), t[j]);
+    int tile = ts;
+    for (; tile + D <= te; tile += D) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        load_tile(min(tile + j + D - 1, tl), t[(j + D - 1) % D]);
+        process(tile + j, t[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j)
+      if (tile + j < te) process(tile + j, t[j]);
+  }
+  float M = fmaxf(m_run, __shfl_xor(m_run, 16));
+  M = fmaxf(M, __shfl_xor(M, 32));
+  {
+    const float e = expf(m_run - M);
+    l_run *= e;
+    o *= e;
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] += __shfl_xor(o[j], 16);
+      o[j] += __shfl_xor(o[j], 32);
+    }
+    m_run = M;
+  }
+  if (NS > 1 && part > 0 && rw == 0) {
+    so[PW + part - 1][row][cc] = o;
+    if (cc == 0) { sm[PW + part - 1][row] = m_run; sl[PW + part - 1][row] = l_run; }
+  }
+  __syncthreads();
+  if (rw != 0 || !live || part > 0) return;
+  {  // fixed order: own state, then the prefix partials 0 .. PW-1 (shared prefix only), then the other suffix shares
+    const int w0 = casc ? 0 : PW;
+    float MM = m_run;
+#pragma unroll
+    for (int w = 0; w < NP; ++w) MM = w >= w0 ? fmaxf(MM, sm[w][row]) : MM;
+    const float e0 = expf(m_run - MM);
+    float L = l_run * e0;
+    f32x4 O = o * e0;
+#pragma unroll
+    for (int w = 0; w < NP; ++w) {
+      const float e = w >= w0 ? expf(sm[w][row] - MM) : 0.f;
+      L += (w >= w0 ? sl[w][row] : 0.f) * e;
+      O += (w >= w0 ? so[w][row][cc] : (f32x4){0.f, 0.f, 0.f, 0.f}) * e;
+    }
+    o = O; l_run = L;
+  }
+  const size_t m = (size_t)b * a.Tq;
+  *(f32x4 *)(a.Y + (((m >> 4) * a.YF + 4 * h + (cc >> 2)) * 64 + 16 * (cc & 3) + (m & 15)) * 4) = o * (1.0f / l_run);
+}
+
 // merges the key splits: thread (query, 4-wide d group)
 static __global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs a) {
   const int bh = blockIdx.x, qb = blockIdx.y;
@@ -2042,7 +2293,8 @@ static __global__ void kv_import_kernel(const float *src, float *Kc, float *Vc, 
   *(f32x4 *)(dst + (((size_t)b * H + h) * cap + t) * 64 + d4 * 4) = v;
 }
 
-static __global__ void kv_export_kernel(float *dst, const float *Kc, const float *Vc, int B, int T, int H, int cap) {
+static __global__ void kv_export_kernel(float *dst, const float *Kc, const float *Vc, int B, int T, int H, int cap,
+                                 const KvPrefix *pre = nullptr, int layer = 0) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = 2L * B * T * H * 16;
   if (i >= total) return;
@@ -2053,19 +2305,21 @@ static __global__ void kv_export_kernel(float *dst, const float *Kc, const float
   int b = r % B; r /= B;
   int which = (int)r;
   const float *src = which ? Vc : Kc;
-  f32x4 v = *(const f32x4 *)(src + (((size_t)b * H + h) * cap + t) * 64 + d4 * 4);
+  f32x4 v;
+  if (pre && t < pre[b].len) v = *(const f32x4 *)(pre[b].kv + ((((size_t)(2 * layer + which)) * H + h) * pre[b].cap + t) * 64 + d4 * 4);
+  else v = *(const f32x4 *)(src + (((size_t)b * H + h) * cap + t) * 64 + d4 * 4);
   *(f32x4 *)(dst + ((((size_t)which * B + b) * T + t) * H + h) * 64 + d4 * 4) = v;
 }
 
 // dst rows <- src rows (src batch 1 broadcasts), whole [L][2][B][H][cap][64] block, equal cap
 // one batch-1 state -> row `row` of a batch state: [planes][1][H][src_cap][64] -> [planes][B][H][dst_cap][64], T positions
 static __global__ void kv_copy_row_kernel(float *dst, const float *src, int planes, int H, int T, int src_cap, int dst_cap,
-                                   int B, int row, int srcB = 1, int src_row = 0) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (plane, head, t, 16 float4)
+                                   int B, int row, int srcB = 1, int src_row = 0, int t0 = 0) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (plane, head, t, 16 float4), positions t0 .. t0 + T - 1
   if (i >= (long)planes * H * T * 16) return;
   const int v = i & 15;
   long r = i >> 4;
-  const int t = r % T; r /= T;
+  const int t = t0 + r % T; r /= T;
   const int h = r % H;
   const int pl = r / H;
   const f32x4 x = *(const f32x4 *)(src + ((((size_t)pl * srcB + src_row) * H + h) * src_cap + t) * 64 + v * 4);

@@ -25,7 +25,7 @@ from test_gpu_parity import ATOL, _maxerr, dev, get_engine
 pytestmark = pytest.mark.gpu
 
 
-def _run_long_context(B, graph):
+def _run_long_context(B, graph, shared_voice=False):
     from oracle import np_oracle as O
 
     cfg, W = synth_weights("en100m")
@@ -35,6 +35,8 @@ def _run_long_context(B, graph):
     Tv, Tt, n1, Tx, n2 = 126, 32, 3, 119, 3  # 126 + 32 = 158 -> steps at 159..161; + 119 = 280 -> steps at 281..283
     rng = np.random.default_rng(1000 + B)
     voice = (rng.standard_normal((B, Tv, eng.D)) * 0.1).astype(np.float32)   # bench.py: N(0, 1) * 0.1 conditioning
+    if shared_voice:
+        voice[:] = voice[:1]
     text = (rng.standard_normal((B, Tt, eng.D)) * 0.3).astype(np.float32)
     extra = (rng.standard_normal((B, Tx, eng.D)) * 0.3).astype(np.float32)
     noise = (rng.standard_normal((n1 + n2, B, eng.ldim)) * 0.7 ** 0.5).astype(np.float32)  # temp 0.7
@@ -47,9 +49,16 @@ def _run_long_context(B, graph):
     nz = torch.zeros(B, eng.ldim, device="cuda:0")
     g = eng.capture_lm_step(st, nz, 1, -4.0, lat, logit, flag) if graph else None
     try:
-        for e in (voice, text):
-            lm.prefill(ost, e)
-            eng.lm_prefill(st, dev(e))
+        lm.prefill(ost, voice)
+        if shared_voice:  # the bench's / the API's way: ONE voice state, cloned (tts_model.py:637-638) - the clones borrow its
+            vs = eng.new_lm_state(1, Tv + 1)  # first 112 keys (KvPrefix) and the decode steps run attn_cascade_kernel
+            eng.lm_prefill(vs, dev(voice[:1]))
+            st.copy_from(vs)
+            vs.close()  # the clones keep the memory alive
+        else:
+            eng.lm_prefill(st, dev(voice))
+        lm.prefill(ost, text)
+        eng.lm_prefill(st, dev(text))
         xo = np.full((B, eng.ldim), np.nan, np.float32)
         step = 0
         for phase, n in ((0, n1), (1, n2)):
@@ -88,6 +97,14 @@ def _run_long_context(B, graph):
 def test_en100m_batch64_vs_oracle_at_bench_contexts():
     """BASELINE config #3: batch 64, contexts 159-161 and 281-283, through the captured step graph the bench replays"""
     _run_long_context(64, graph=True)
+
+
+@pytest.mark.parametrize("B,graph", [(64, True), (21, False)])
+def test_en100m_cloned_voice_vs_oracle_at_bench_contexts(B, graph):
+    """the same, with every sequence cloned from ONE voice state as bench.py and the API do: shared prefix keys
+    (pointer select in the prefill attention) and the cascade decode attention (MFMA prefix tiles + per-sequence suffix),
+    against the oracle, which knows nothing of sharing; 21 = a group of 4 sequences that overhangs the batch"""
+    _run_long_context(B, graph, shared_voice=True)
 
 
 def test_en100m_batch3_vs_oracle_at_bench_contexts():
