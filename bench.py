@@ -306,8 +306,10 @@ def one_voice_throughput(eng, args, n_utt, seed, table_id, profile):
                                         achieved_GBs=v["bytes"] / v["count"] / avg_s / 1e9,
                                         frac=v["bytes"] / v["count"] / avg_s / 1e9 / HBM_PEAK_GBS,
                                         unique_bytes_per_launch=uniq, achieved_unique_GBs=uniq / avg_s / 1e9,
-                                        frac_unique=uniq / avg_s / 1e9 / HBM_PEAK_GBS, traffic=pmc_traffic(k, table_id),
-                                        rocprof_pipelined_avg_us=rocprof_avg_us("attn_cascade_kernel"))
+                                        frac_unique=uniq / avg_s / 1e9 / HBM_PEAK_GBS,
+                                        traffic=pmc_traffic(k, table_id, PMC_FILE_ONE),
+                                        rocprof_pipelined_avg_us=rocprof_avg_us("attn_cascade_kernel", STATS_FILE_ONE),
+                                        rocprof_file="profiles/" + STATS_FILE_ONE)
         out["kernel_sum_ms_per_step"] = sum(r["total_ms"] for r in rows) / nst
     return out, job
 
@@ -405,15 +407,17 @@ def tune_table_id(eng) -> str:
 
 PMC_FILE = "r03_pmc_traffic.json"     # tools/profile_round.sh -> profiles/ (FETCH_SIZE / WRITE_SIZE passes of this round's build)
 STATS_FILE = "r03_b64_kernel_stats.csv"  # rocprofv3 --kernel-trace --stats of the headline command
+PMC_FILE_ONE = "r03_onevoice_pmc_traffic.json"     # the same passes with --voices one (rows share the voice's keys)
+STATS_FILE_ONE = "r03_onevoice_kernel_stats.csv"
 
 
-def pmc_traffic(name, table_id):
+def pmc_traffic(name, table_id, pmc_file=None):
     """HBM bytes per launch of `name` from the committed PMC passes (profiles/r03_pmc_traffic.json: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 calibration).  PMC counters cannot be
     read from inside this process, so the file is a replay; it is only used when it was measured on the SAME tile
     table as this run (its `tune_table_id` stamp), else None."""
     try:
-        with open(os.path.join(REPO, "profiles", PMC_FILE)) as f:
+        with open(os.path.join(REPO, "profiles", pmc_file or PMC_FILE)) as f:
             d = json.load(f)
         if d.get("tune_table_id") != table_id:
             return None
@@ -422,13 +426,13 @@ def pmc_traffic(name, table_id):
         return None
 
 
-def rocprof_avg_us(kernel_substr):
+def rocprof_avg_us(kernel_substr, stats_file=None):
     """average duration of a kernel over the WHOLE pipelined bench run from the committed rocprofv3 --stats summary (the
     cross-check SURVEY 8d asks for: both streams running, contexts 159-283), or None"""
     import csv
 
     try:
-        with open(os.path.join(REPO, "profiles", STATS_FILE)) as f:
+        with open(os.path.join(REPO, "profiles", stats_file or STATS_FILE)) as f:
             for r in csv.DictReader(f):
                 if kernel_substr in r["Name"]:
                     return float(r["AverageNs"]) / 1e3

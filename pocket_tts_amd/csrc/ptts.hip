@@ -178,6 +178,7 @@ struct ptts_lm_state {
   KvPrefix *d_pre = nullptr;
   std::vector<KvPrefix> h_pre;
   std::vector<ptts_lm_state *> pre_owner;
+  int casc_mode = -1;   // decode attention: -1 = cascade kernel iff rows borrow prefixes now (eager steps), 0 / 1 forced (captures)
   int n_pre = 0;        // rows of this state that have a prefix
   int borrowers = 0;    // rows of OTHER states whose prefix is this state's cache
   bool zombie = false;
@@ -225,6 +226,10 @@ struct ptts_mimi_state {
 struct ptts_graph {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  // second capture of an LM step for states whose rows share a prefix (attn_cascade_kernel instead of the per-row decode
+  // attention): ptts_graph_launch picks by the state's borrow count, which the host knows
+  hipGraph_t graph_c = nullptr;
+  hipGraphExec_t exec_c = nullptr;
   ptts_lm_state *lm = nullptr;
   ptts_mimi_state *mimi = nullptr;
   hipStream_t cap_stream = nullptr;
@@ -2010,7 +2015,7 @@ static void lm_layers(hipStream_t st, ptts_engine *e, ptts_lm_state *s, Scratch 
     t.x_in = sc.x; t.x = sc.x; t.x_out = sc.x; t.out_ds = 0; t.par = nullptr;
     t.h = sc.h; t.ao = sc.ao; t.ff = sc.ff; t.q = sc.q; t.part = sc.part;
     t.Kc = s->K(l); t.Vc = s->V(l); t.offset = s->offset; t.rope = sc.rope;
-    t.pre = s->d_pre; t.layer = l; t.cascade = e->opt_share_prefix ? e->opt_cascade : 0;
+    t.pre = s->d_pre; t.layer = l; t.cascade = e->opt_share_prefix && (s->casc_mode < 0 ? s->n_pre > 0 : s->casc_mode > 0) ? e->opt_cascade : 0;
     t.kv_keys = 0;
     for (int b = 0; b < s->B; ++b) t.kv_keys += s->h_off[b] + Tq;
     t.tag = "lm";
@@ -2855,15 +2860,29 @@ extern "C" int ptts_encode_voice(ptts_engine *e, const float *d_audio, int64_t n
 // ------------------------------------------------------------------------------------------------
 // hipGraph capture
 template <typename F>
-static int capture(ptts_engine *e, ptts_graph *g, F &&body) {
-  HIPCHK(hipStreamCreateWithFlags(&g->cap_stream, hipStreamNonBlocking));
+static int capture_into(ptts_graph *g, hipGraph_t *graph, hipGraphExec_t *exec, F &&body) {
+  if (!g->cap_stream) HIPCHK(hipStreamCreateWithFlags(&g->cap_stream, hipStreamNonBlocking));
   HIPCHK(hipStreamBeginCapture(g->cap_stream, hipStreamCaptureModeThreadLocal));
   int r = body(g->cap_stream);
-  hipError_t er = hipStreamEndCapture(g->cap_stream, &g->graph);
+  hipError_t er = hipStreamEndCapture(g->cap_stream, graph);
   if (r < 0) return r;
   HIPCHK(er);
-  HIPCHK(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
+  HIPCHK(hipGraphInstantiate(exec, *graph, nullptr, nullptr, 0));
   return 0;
+}
+// a graph with an FlowLM step inside is captured twice when its state may come to share prefixes: rows on their own / cascade
+template <class F>
+static int capture(ptts_engine *e, ptts_graph *g, F &&body) {
+  ptts_lm_state *s = g->lm;
+  const bool two = s && e->opt_share_prefix && e->opt_cascade && !e->opt_lm_cluster && s->B >= 16;
+  if (s) s->casc_mode = 0;
+  int r = capture_into(g, &g->graph, &g->exec, body);
+  if (r >= 0 && two) {
+    s->casc_mode = 1;
+    r = capture_into(g, &g->graph_c, &g->exec_c, body);
+  }
+  if (s) s->casc_mode = -1;
+  return r;
 }
 
 extern "C" int ptts_graph_capture_lm_step(ptts_engine *e, ptts_lm_state *s, const float *d_noise, int32_t lsd_steps,
@@ -2954,7 +2973,7 @@ extern "C" int ptts_graph_launch(ptts_graph *g, void *stream) {
       g->cu_checked = S(e, stream);
     }
     CoopGuard guard(e->device, S(e, stream), g->coop_wgs, e->n_cus);
-    HIPCHK(hipGraphLaunch(g->exec, S(e, stream)));
+    HIPCHK(hipGraphLaunch(g->exec_c && g->lm && g->lm->n_pre > 0 ? g->exec_c : g->exec, S(e, stream)));
     if (guard.finish() < 0) return fail(-2, "graph launch: could not chain the cooperative launch behind its predecessor");
   }
   if (g->lm) for (int b = 0; b < g->lm->B; ++b) g->lm->h_off[b] += g->lm->h_active[b];
@@ -2967,6 +2986,8 @@ extern "C" void ptts_graph_destroy(ptts_graph *g) {
   if (g->lm && g->exec && g->lm->n_graphs > 0) g->lm->n_graphs -= 1;
   if (g->exec) hipGraphExecDestroy(g->exec);
   if (g->graph) hipGraphDestroy(g->graph);
+  if (g->exec_c) hipGraphExecDestroy(g->exec_c);
+  if (g->graph_c) hipGraphDestroy(g->graph_c);
   if (g->cap_stream) hipStreamDestroy(g->cap_stream);
   delete g;
 }
