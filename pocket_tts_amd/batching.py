@@ -200,9 +200,22 @@ class ContinuousBatcher:
         groups: dict = {}
         for job in take:
             groups.setdefault((id(job.voice), job.tokens.shape[1]), []).append(job)
-        for jobs in groups.values():
+        # slots: rows of one voice share its keys (KvPrefix) and the decode attention scores a shared prefix once per 4
+        # NEIGHBOURING rows (attn_cascade_kernel), so a job prefers a 4-row group that holds only its own voice
+        voice_of = {b: id(self.slot[b].voice) for b in range(self.B) if self.slot[b] is not None}
+
+        def pick(vid):
+            def score(b):
+                mates = [voice_of[r] for r in range(b & ~3, min(self.B, (b & ~3) + 4)) if r in voice_of]
+                return (any(v != vid for v in mates), -sum(v == vid for v in mates), b)
+            b = min(free, key=score)
+            free.remove(b)
+            voice_of[b] = vid
+            return b
+
+        for (vid, _), jobs in sorted(groups.items(), key=lambda kv: kv[0][0]):
             try:
-                self._admit_group(jobs, [free.pop(0) for _ in jobs])
+                self._admit_group(jobs, [pick(vid) for _ in jobs])
             except (ValueError, KeyError, IndexError, TypeError) as e:
                 if len(jobs) == 1:
                     # a bad request (malformed voice state, capacity): fail THIS request, keep serving the others.  The

@@ -233,6 +233,18 @@ class TTSModel:
             model_states = [model_states] * B
         if len(model_states) != B or B == 0:
             raise ValueError("need one voice state per text")
+        # rows of one voice next to each other: they share the voice's keys (KvPrefix), and the decode attention scores a
+        # shared prefix once per 4 neighbouring rows (attn_cascade_kernel)
+        first: dict = {}
+        for i, m in enumerate(model_states):
+            first.setdefault(id(m), i)
+        order = sorted(range(B), key=lambda i: first[id(model_states[i])])
+        if order != list(range(B)):
+            got = self.generate_audio_batch([model_states[i] for i in order], [texts[i] for i in order], frames_after_eos)
+            res = [None] * B
+            for pos, i in enumerate(order):
+                res[i] = got[pos]
+            return res
         toks, gens, faes, t0s = [], [], [], []
         for text, ms_ in zip(texts, model_states):
             # the reference tokenises the chunk text as split_into_best_sentences returns it (stripped)

@@ -154,6 +154,10 @@ def test_voice_state_from_wav_file(model, fx, tmp_path):
     assert int(state["transformer.layers.0.self_attn"]["offset"][0]) == 14
 
 
+TEXTS = ["Hello world. This is a test.", "ok", "This is a longer sentence, with several clauses, to test it.",
+         "How are you today?", "Short one.", "Another request arrives while the others are running.", "Yes."]
+
+
 def test_generate_audio_batch_matches_single_utterances(model, fx):
     """Mixed-length batch (different texts, hence different prompt lengths and per-row cache offsets, different
     EOS steps and frame counts) against one-by-one generation at temp 0."""
@@ -170,6 +174,36 @@ def test_generate_audio_batch_matches_single_utterances(model, fx):
         assert np.abs(a.numpy() - b.numpy()).max() < 5e-4, t
 
 
+def test_two_voices_interleaved_share_prefixes_and_match_single_utterances(model, fx):
+    """20 requests alternating between TWO voices, in one `generate_audio_batch` call and through 16 batcher slots:
+    rows of a voice are placed next to each other, borrow their voice's keys (KvPrefix) and the decode steps run the
+    cascade attention over groups of 4 rows - including the group where the two voices meet (per-row path for the
+    stranger) and, in the batcher, groups whose rows were re-admitted at different positions.  Every waveform must
+    reproduce the one-by-one result at temp 0, in the caller's order."""
+    from pocket_tts_amd.batching import ContinuousBatcher
+
+    d = model.engine.D
+    va = model.get_state_for_audio_prompt(G / "e2e_voice.safetensors")
+    vb = model.get_state_for_conditioning(torch.randn(1, 45, d, generator=torch.Generator().manual_seed(5)) * 0.1)
+    texts = [TEXTS[i % len(TEXTS)] for i in range(20)]
+    voices = [va if i % 2 == 0 else vb for i in range(20)]
+    singles = [model.generate_audio(v, t) for v, t in zip(voices, texts)]
+    batch = model.generate_audio_batch(voices, texts)
+    for i, (a, b) in enumerate(zip(singles, batch)):
+        assert a.shape == b.shape, (i, a.shape, b.shape)
+        assert np.abs(a.numpy() - b.numpy()).max() < 5e-4, i
+    cb = ContinuousBatcher(model, slots=16, capacity=512)
+    try:
+        reqs = [cb.submit(v, t) for v, t in zip(voices, texts)]
+        cb.run_until_idle()
+        outs = [r.result() for r in reqs]
+    finally:
+        cb.close()
+    for i, (a, b) in enumerate(zip(singles, outs)):
+        assert a.shape == b.shape, (i, a.shape, b.shape)
+        assert np.abs(a.numpy() - b.numpy()).max() < 5e-4, i
+
+
 def test_generate_audio_batch_validates_inputs(model):
     state = model.get_state_for_audio_prompt(G / "e2e_voice.safetensors")
     with pytest.raises(ValueError):
@@ -178,8 +212,6 @@ def test_generate_audio_batch_validates_inputs(model):
         model.generate_audio_batch(state, ["   "])
 
 
-TEXTS = ["Hello world. This is a test.", "ok", "This is a longer sentence, with several clauses, to test it.",
-         "How are you today?", "Short one.", "Another request arrives while the others are running.", "Yes."]
 
 
 def test_continuous_batching_join_leave_matches_single(model, fx):
