@@ -143,6 +143,7 @@ struct ptts_engine {
   int opt_k_rotate = 0;
   long fuse_res_min_rows = 0;
   int opt_codec_lds_target = 56 * 1024;  // see lds_pad()
+  int opt_single_store = 1;  // SEANet transposed convs store their raw output once; the next conv applies ELU on its operand read
   int opt_fuse_res = 1;  // SEANet residual blocks of stages 2 and 3 as one launch each (gemm_lds_kernel<.., NT2>)
   int opt_flow_max_cus = 128;  // resident workgroups of the single-launch flow MLP (<= the CUs its stream may use)
   int opt_share_prefix = 1;    // clones of a batch-1 state share its keys / values (KvPrefix) instead of copying them
@@ -483,6 +484,7 @@ static void launch_cfg(hipStream_t st, const GemmArgs &a, int pre) {
     case PRE_NONE: LDS_LAUNCH((gemm_kernel<TN, TM, WK, WN, WM, PRE_NONE>), grid, block, dyn, st, a); break;
     case PRE_LNFOLD: LDS_LAUNCH((gemm_kernel<TN, TM, WK, WN, WM, PRE_LNFOLD>), grid, block, dyn, st, a); break;
     case PRE_LNMOD: LDS_LAUNCH((gemm_kernel<TN, TM, WK, WN, WM, PRE_LNMOD>), grid, block, dyn, st, a); break;
+    case PRE_ELU: LDS_LAUNCH((gemm_kernel<TN, TM, WK, WN, WM, PRE_ELU>), grid, block, dyn, st, a); break;
     default: LDS_LAUNCH((gemm_kernel<TN, TM, WK, WN, WM, PRE_ADDSILU>), grid, block, dyn, st, a); break;
   }
 }
@@ -498,10 +500,11 @@ static void launch_lds(hipStream_t st, const GemmArgs &a, int pre) {
     if (variant == 1 && g_lds_target) {
       const unsigned dyn3 = lds_pad(3 * (BMT + BNT) * 2 * 1024);
       if (pre == PRE_LNFOLD) gemm_lds_kernel<BMT, BNT, 2, PRE_LNFOLD, 3><<<grid, 256, dyn3, st>>>(a);
+      else if (pre == PRE_ELU) gemm_lds_kernel<BMT, BNT, 2, PRE_ELU, 3><<<grid, 256, dyn3, st>>>(a);
       else gemm_lds_kernel<BMT, BNT, 2, PRE_NONE, 3><<<grid, 256, dyn3, st>>>(a);
       return;
     }
-    if (variant == 2 && g_lds_target && a.KF % 4 == 0) {
+    if (variant == 2 && g_lds_target && a.KF % 4 == 0 && pre != PRE_ELU) {
       const unsigned dyn4 = lds_pad(2 * (BMT + BNT) * 4 * 1024);
       if (pre == PRE_LNFOLD) gemm_lds_kernel<BMT, BNT, 4, PRE_LNFOLD><<<grid, 256, dyn4, st>>>(a);
       else gemm_lds_kernel<BMT, BNT, 4, PRE_NONE><<<grid, 256, dyn4, st>>>(a);
@@ -510,6 +513,7 @@ static void launch_lds(hipStream_t st, const GemmArgs &a, int pre) {
   }
   const unsigned dyn = lds_pad(2 * (BMT + BNT) * 2 * 1024);
   if (pre == PRE_LNFOLD) LDS_LAUNCH((gemm_lds_kernel<BMT, BNT, 2, PRE_LNFOLD>), grid, dim3(256), dyn, st, a);
+  else if (pre == PRE_ELU) LDS_LAUNCH((gemm_lds_kernel<BMT, BNT, 2, PRE_ELU>), grid, dim3(256), dyn, st, a);
   else LDS_LAUNCH((gemm_lds_kernel<BMT, BNT, 2, PRE_NONE>), grid, dim3(256), dyn, st, a);
 }
 
@@ -561,7 +565,7 @@ static bool cfg_valid(int cfg, const GemmArgs &a, int pre) {
     if (a.KF % ((a.wfmt == 1 ? 4 : 2) * s[2])) return false;
   }
   if (s[2] == 0) {  // LDS-staged: two k-fragments per stage, plain or LN-folded operand only
-    if (a.KF % 2 || (pre != PRE_NONE && pre != PRE_LNFOLD)) return false;
+    if (a.KF % 2 || (pre != PRE_NONE && pre != PRE_LNFOLD && pre != PRE_ELU)) return false;
     return a.MT >= s[1] && 2 * a.NT >= s[0];
   }
   const int tn = s[0] * s[3], tm = s[1] * s[4];
@@ -754,7 +758,7 @@ static void launch_gemm(hipStream_t st, const GemmArgs &a_in, int pre) {
   const long wgs = sh[2] == 0 ? (long)cdiv(a.NT, sh[0]) * cdiv(a.MT, sh[1])
                               : (long)cdiv(a.NT, sh[0] * sh[3]) * cdiv(a.MT, sh[1] * sh[4]);
   const long threads = wgs * (sh[2] == 0 ? 256 : 64 * sh[2] * sh[3] * sh[4]);
-  ProfScope ps(st, std::string(kCfgName[cfg]) + (pre == PRE_NONE ? "" : pre == PRE_LNFOLD ? "+ln" : pre == PRE_LNMOD ? "+lnmod" : "+addsilu") +
+  ProfScope ps(st, std::string(kCfgName[cfg]) + (pre == PRE_NONE ? "" : pre == PRE_LNFOLD ? "+ln" : pre == PRE_LNMOD ? "+lnmod" : pre == PRE_ELU ? "+elu" : "+addsilu") +
   (a.wfmt == 1 ? "+q8" : a.wfmt == 2 ? "+b16" : a.wfmt == 3 ? "+split" : "") + "@" + std::to_string(threads), bytes, 2.0 * M * N * K);
   launch_by_cfg(st, a, pre, cfg);
 }
@@ -765,13 +769,18 @@ static bool resblock_fusable(const Lin &A, const Lin &Bl, int MT) {
   return !A.wq && !Bl.wq && A.bias && Bl.bias && Bl.ntaps == 1 && Bl.KF == A.NT && A.KF % 2 == 0 && MT >= 4 &&
          ((A.NT == 2 && Bl.NT == 4) || (A.NT == 4 && Bl.NT == 8));
 }
-static void launch_resblock(hipStream_t st, GemmArgs a, const Lin &Bl) {
+static void launch_resblock(hipStream_t st, GemmArgs a, const Lin &Bl, int pre = PRE_NONE) {
   a.zeros = g_zeros;
   a.W2 = Bl.w; a.bias2 = Bl.bias;
   const double M = a.M, K = a.KF * 16.0, N = a.NT * 16.0, N2 = Bl.NT * 16.0;
-  ProfScope ps(st, std::string(a.NT == 2 ? "resblock<2,4>" : "resblock<4,8>") + "@" + std::to_string((long)cdiv(a.MT, 4) * 256),
-               4.0 * (N * K + N2 * N + M * a.CF * 16.0 + 2.0 * M * N2), 2.0 * M * N * K + 2.0 * M * N2 * N);
+  ProfScope ps(st, std::string(a.NT == 2 ? "resblock<2,4>" : "resblock<4,8>") + (pre == PRE_ELU ? "+elu" : "") + "@" + std::to_string((long)cdiv(a.MT, 4) * 256),
+               4.0 * (N * K + N2 * N + M * a.CF * 16.0 + (pre == PRE_ELU ? 1.0 : 2.0) * M * N2), 2.0 * M * N * K + 2.0 * M * N2 * N);
   dim3 grid(1, cdiv(a.MT, 4));
+  if (pre == PRE_ELU) {
+    if (a.NT == 2) LDS_LAUNCH((gemm_lds_kernel<4, 2, 2, PRE_ELU, 2, 4>), grid, dim3(256), lds_pad(24 * 1024), st, a);
+    else LDS_LAUNCH((gemm_lds_kernel<4, 4, 2, PRE_ELU, 2, 8>), grid, dim3(256), lds_pad(32 * 1024), st, a);
+    return;
+  }
   if (a.NT == 2) LDS_LAUNCH((gemm_lds_kernel<4, 2, 2, PRE_NONE, 2, 4>), grid, dim3(256), lds_pad(24 * 1024), st, a);
   else LDS_LAUNCH((gemm_lds_kernel<4, 4, 2, PRE_NONE, 2, 8>), grid, dim3(256), lds_pad(32 * 1024), st, a);
 }
@@ -1002,6 +1011,7 @@ static int init_engine_options(ptts_engine *e, int device) {
   if (const char *v = getenv("PTTS_K_ROTATE")) e->opt_k_rotate = atoi(v) != 0;
   if (const char *v = getenv("PTTS_FUSE_RES")) e->opt_fuse_res = atoi(v) != 0;
   if (const char *v = getenv("PTTS_SHARE_PREFIX")) e->opt_share_prefix = atoi(v) != 0;
+  if (const char *v = getenv("PTTS_SINGLE_STORE")) e->opt_single_store = atoi(v) != 0;
   if (const char *v = getenv("PTTS_CASCADE")) e->opt_cascade = atoi(v);
   if (const char *v = getenv("PTTS_FLOW_MAX_CUS")) e->opt_flow_max_cus = std::max(8, atoi(v));
   e->opt_flow_max_cus = std::min(e->opt_flow_max_cus, e->n_cus);  // a cooperative grid never exceeds the device
@@ -2554,17 +2564,24 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
     a.epi = EPI_CONVTR; a.cout = cout; a.stride = c.ratios[i];
     a.Y = s->cbuf[i]; a.Ydstride = s->c_stride[i]; a.YF = cout / 16; a.act = ACT_ELU;
     a.Yraw = s->craw[i]; a.Yrawdstride = 0;  // raw value = the resnet block's skip input
+    // "single_store": the transposed conv stores its RAW output once (the block's skip input); the k3 conv that follows
+    // applies ELU to its operand fragments as it reads them (PRE_ELU).  Saves one write and one read of every stage output
+    // (107 MB per 64-sequence frame): +1.x % pipelined; fp32 weights only
+    const bool single = e->opt_single_store && !g_use_split && !e->res_a[i].wq && !e->res_a[i].wb16;
+    const int pre_a = single ? PRE_ELU : PRE_NONE;
+    if (single) { a.act = ACT_NONE; a.Yraw = nullptr; }
     launch_gemm(st, a, PRE_NONE);
     if (e->opt_fuse_res && resblock_fusable(e->res_a[i], e->res_b[i], MTout) && (long)MTout * 16 >= e->fuse_res_min_rows) {
       SITE(sn[i][1]);
       a = mk_gemm(e->res_a[i], s->cbuf[i], cout / 16, MTout, B * Tout);
       a.Xdstride = s->c_stride[i]; a.T = Tout; a.par = s->frame; a.act = ACT_ELU;
       a.R = s->craw[i]; a.Rdstride = 0; a.RF = cout / 16; a.act2 = ACT_ELU;
+      if (single) { a.R = s->cbuf[i]; a.Rdstride = s->c_stride[i]; }
       a.Y = s->sbuf[i]; a.Ydstride = s->s_stride[i]; a.YF = cout / 16;
       // a split-bf16 engine keeps the FUSED fp32 residual blocks: the unfused split pair is slower (stage 3: 34 + 35 us
       // against 43 us fused, stage 2: 25 + 21 against 32; gpurun_out r3 profile), the block is bound by its activations
       a.W = e->res_a[i].w; a.Wq = nullptr; a.wfmt = 0;
-      launch_resblock(st, a, e->res_b[i]);
+      launch_resblock(st, a, e->res_b[i], pre_a);
       xin = s->sbuf[i];
       xds = s->s_stride[i];
       mult /= 2;
@@ -2574,11 +2591,12 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
     a = mk_gemm(e->res_a[i], s->cbuf[i], cout / 16, MTout, B * Tout);
     a.Xdstride = s->c_stride[i]; a.T = Tout; a.par = s->frame;
     a.Y = s->rbuf[i]; a.YF = hid / 16; a.act = ACT_ELU;
-    launch_gemm(st, a, PRE_NONE);
+    launch_gemm(st, a, pre_a);
     SITE(sn[i][2]);
     a = mk_gemm(e->res_b[i], s->rbuf[i], hid / 16, MTout, B * Tout);
     a.T = Tout; a.par = s->frame;
     a.epi = EPI_RES; a.R = s->craw[i]; a.Rdstride = 0; a.RF = cout / 16; a.act = ACT_ELU;
+    if (single) { a.R = s->cbuf[i]; a.Rdstride = s->c_stride[i]; }
     a.Y = s->sbuf[i]; a.Ydstride = s->s_stride[i]; a.YF = cout / 16;
     launch_gemm(st, a, PRE_NONE);
     xin = s->sbuf[i];
@@ -3002,6 +3020,7 @@ extern "C" int ptts_set_option(ptts_engine *e, const char *key, int32_t value) {
   else if (k == "k_rotate") e->opt_k_rotate = value != 0;
   else if (k == "fuse_res") e->opt_fuse_res = value != 0;
   else if (k == "share_prefix") e->opt_share_prefix = value != 0;
+  else if (k == "single_store") e->opt_single_store = value != 0;
   else if (k == "prefix_cascade") e->opt_cascade = value == 1 ? 423 : value;
   else if (k == "codec_lds_target") {
     if (value < 0 || value > 64 * 1024) return fail(-1, "codec_lds_target must be in [0, 65536]");
@@ -3155,7 +3174,9 @@ extern "C" int64_t ptts_debug_read(ptts_engine *e, void *state, int32_t is_mimi,
       int mult = 8 >> stage;
       K = mult * c.n_filters / 2;
       M = B * s->rows[stage + 1];
-      src = is_res ? s->sbuf[stage] + par * s->s_stride[stage] : s->craw[stage];
+      const ptts_engine *en = s->e;
+      const bool single = en->opt_single_store && !en->codec_split && !en->res_a[stage].wq && !en->res_a[stage].wb16;
+      src = is_res ? s->sbuf[stage] + par * s->s_stride[stage] : single ? s->cbuf[stage] + par * s->c_stride[stage] : s->craw[stage];
     }
     F = K / 16;
   }

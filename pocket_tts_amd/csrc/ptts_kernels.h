@@ -70,6 +70,10 @@ enum { ACT_NONE = 0, ACT_GELU, ACT_SILU, ACT_ELU };
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float elu_f(float x) { return x > 0.0f ? x : expm1f(x); }
+// ELU applied by a CONSUMER on its operand fragments (PRE_ELU: the producer stored the raw value once): evaluated once per
+// tap and per wave that reads the fragment, so it has to be cheap: exp on the transcendental unit, absolute error <= 1.2e-7
+// (the outputs are in (-1, 0]); expm1f's relative accuracy near 0 buys nothing against the 2e-4 parity tolerance
+__device__ __forceinline__ float elu_fast_f(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
 // ELU in producer epilogues: exp(x) - 1 has an ABSOLUTE error of ~1e-7 near 0, far inside the 2e-4 parity bound
 __device__ __forceinline__ float elu_fast(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
 
@@ -201,7 +205,7 @@ __device__ __forceinline__ void tile_of_block(int swz, int &bx, int &by) {
 template <int PRE>
 __device__ __forceinline__ f32x4 pre4(f32x4 x, const float *prevec, int kf, int lane) {
   if (PRE == PRE_ELU) {
-    x.x = elu_f(x.x); x.y = elu_f(x.y); x.z = elu_f(x.z); x.w = elu_f(x.w);
+    x.x = elu_fast_f(x.x); x.y = elu_fast_f(x.y); x.z = elu_fast_f(x.z); x.w = elu_fast_f(x.w);
   } else if (PRE == PRE_ADDSILU) {
     f32x4 t = *(const f32x4 *)(prevec + 16 * kf + 4 * (lane >> 4));
     x.x = silu_f(x.x + t.x); x.y = silu_f(x.y + t.y); x.z = silu_f(x.z + t.z); x.w = silu_f(x.w + t.w);
@@ -873,7 +877,7 @@ template <int BMT, int BNT, int KC, int PRE, int NS = 2, int NT2 = 0>
 __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
   if constexpr (PTTS_ABLATE & 128) return;
   static_assert(BMT % 4 == 0 && BNT % 2 == 0 && (BNT * KC) % 4 == 0, "tile shape");
-  static_assert(NT2 == 0 || (PRE == PRE_NONE && BMT * BNT <= NS * (BMT + BNT) * KC && NT2 % 4 == 0), "fused tail");
+  static_assert(NT2 == 0 || ((PRE == PRE_NONE || PRE == PRE_ELU) && BMT * BNT <= NS * (BMT + BNT) * KC && NT2 % 4 == 0), "fused tail");
   static_assert(NS >= 2 && NS <= 4, "stage count");
   constexpr int WMT = BMT / 2, WNT = BNT / 2;  // tiles per wave
   constexpr int NX = BMT * KC, NFRAG = (BMT + BNT) * KC;
@@ -1006,7 +1010,11 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
 #pragma unroll
       for (int i = 0; i < WNT; ++i) w[i] = lds[cur][NX + kc * BNT + wn * WNT + i][lane];
     };
-    auto mm = [&](const f32x4 *x, const f32x4 *w) {
+    auto mm = [&](f32x4 *x, const f32x4 *w) {
+      if constexpr (PRE == PRE_ELU) {  // the producer stored the raw value once (it is also the block's skip input)
+#pragma unroll
+        for (int j = 0; j < WMT; ++j) x[j] = pre4<PRE_ELU>(x[j], nullptr, 0, lane);
+      }
       if constexpr (PRE == PRE_LNFOLD) {
 #pragma unroll
         for (int j = 0; j < WMT; ++j) {
