@@ -231,6 +231,10 @@ int ptts_tune_import(ptts_engine *e, const char *text);
  *   "flow_max_cus"  [PTTS_FLOW_MAX_CUS, 128] resident workgroups of the cooperative flow launch (8..CUs of the device): at most the number
  *                                           of CUs its stream may use (a CU-masked FlowLM stream needs it lowered; fewer is
  *                                           slower in the shared pipeline too: 128 -> 0.852, 64 -> 0.904, 32 -> 1.010 ms per step)
+ *   "single_store"  [PTTS_SINGLE_STORE, 1]  1 = a SEANet transposed conv stores its RAW output once (it is the residual block's skip
+ *                                           input) and the k3 conv that follows applies ELU to its operand fragments as it reads
+ *                                           them; 0 = the producer stores raw + ELU'd copies (rounds 1-2).  fp32 codec only;
+ *                                           -107 MB of HBM traffic per 64-sequence frame, +1.4 % pipelined throughput
  *   "share_prefix"  [PTTS_SHARE_PREFIX, 1]  1 = ptts_lm_state_copy / _copy_row(_from) from a ONE-sequence state (a voice state) do
  *                                           not copy its first T & ~15 keys / values: the clone's rows BORROW them (the
  *                                           attention kernels read those key tiles from the owner's cache), so the
