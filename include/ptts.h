@@ -235,6 +235,12 @@ int ptts_tune_import(ptts_engine *e, const char *text);
  *                                           input) and the k3 conv that follows applies ELU to its operand fragments as it reads
  *                                           them; 0 = the producer stores raw + ELU'd copies (rounds 1-2).  fp32 codec only;
  *                                           -107 MB of HBM traffic per 64-sequence frame, +1.4 % pipelined throughput
+ *   "fuse_pcm"      [PTTS_FUSE_PCM, 1]      1 = SEANet's last conv (n_filters -> 1 sample) runs in the epilogue of the last stage's fused
+ *                                           residual block (per 64-row tile: partial sums + a carry for the next tile's first two
+ *                                           samples; a small kernel adds carries and bias and writes the PCM); 0 = a separate
+ *                                           conv over the stored block output.  fp32 codec, en100m-shaped last stage only
+ *   "debug_taps"    [-, 0]                  1 = buffers that fused kernels keep on chip are also stored, so that ptts_debug_read can
+ *                                           return every stage (parity tests); reading such a buffer without it fails (-1)
  *   "share_prefix"  [PTTS_SHARE_PREFIX, 1]  1 = ptts_lm_state_copy / _copy_row(_from) from a ONE-sequence state (a voice state) do
  *                                           not copy its first T & ~15 keys / values: the clone's rows BORROW them (the
  *                                           attention kernels read those key tiles from the owner's cache), so the

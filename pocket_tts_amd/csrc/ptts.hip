@@ -143,6 +143,8 @@ struct ptts_engine {
   int opt_k_rotate = 0;
   long fuse_res_min_rows = 0;
   int opt_codec_lds_target = 56 * 1024;  // see lds_pad()
+  int opt_fuse_pcm = 1;      // SEANet's last conv inside the last stage's fused residual block (its output tile never leaves the CU)
+  int opt_debug_taps = 0;    // materialise buffers that fused kernels keep on chip (ptts_debug_read of every stage)
   int opt_single_store = 1;  // SEANet transposed convs store their raw output once; the next conv applies ELU on its operand read
   int opt_fuse_res = 1;  // SEANet residual blocks of stages 2 and 3 as one launch each (gemm_lds_kernel<.., NT2>)
   int opt_flow_max_cus = 128;  // resident workgroups of the single-launch flow MLP (<= the CUs its stream may use)
@@ -219,6 +221,9 @@ struct ptts_mimi_state {
   int rows[4];  // rows per sequence at each SEANet stage
   float *pcm_dbg;
   int16_t *pcm_i16 = nullptr;
+  // fused last stage ("fuse_pcm"): per-row partial PCM + what each 64-row tile leaves for the first two rows of the next
+  float *pcm_part = nullptr, *pcm_carry = nullptr;
+  long pcm_cstride = 0;
   size_t kv_plane() const { return (size_t)B * e->cfg.m_heads * e->ring * 64; }
   float *K(int l) { return kv + (size_t)(2 * l) * kv_plane(); }
   float *V(int l) { return kv + (size_t)(2 * l + 1) * kv_plane(); }
@@ -1012,6 +1017,7 @@ static int init_engine_options(ptts_engine *e, int device) {
   if (const char *v = getenv("PTTS_FUSE_RES")) e->opt_fuse_res = atoi(v) != 0;
   if (const char *v = getenv("PTTS_SHARE_PREFIX")) e->opt_share_prefix = atoi(v) != 0;
   if (const char *v = getenv("PTTS_SINGLE_STORE")) e->opt_single_store = atoi(v) != 0;
+  if (const char *v = getenv("PTTS_FUSE_PCM")) e->opt_fuse_pcm = atoi(v) != 0;
   if (const char *v = getenv("PTTS_CASCADE")) e->opt_cascade = atoi(v);
   if (const char *v = getenv("PTTS_FLOW_MAX_CUS")) e->opt_flow_max_cus = std::max(8, atoi(v));
   e->opt_flow_max_cus = std::min(e->opt_flow_max_cus, e->n_cus);  // a cooperative grid never exceeds the device
@@ -2264,6 +2270,9 @@ static int build_mimi_state(ptts_engine *e, ptts_mimi_state *s) {
     mult /= 2;
   }
   CHK(dallocT(nullptr, &s->pcm_dbg, (size_t)B * rows));
+  CHK(dallocT(nullptr, &s->pcm_part, (size_t)B * rows));
+  s->pcm_cstride = (long)cdiv(B * rows, 64) * 2;
+  CHK(dallocT(nullptr, &s->pcm_carry, (size_t)2 * s->pcm_cstride));
   HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
 }
@@ -2274,7 +2283,7 @@ extern "C" void ptts_mimi_state_destroy(ptts_mimi_state *s) {
   hipDeviceSynchronize();
   hipFree(s->frame); hipFree(s->offset); hipFree(s->kv); hipFree(s->zl); hipFree(s->zq); hipFree(s->u0);
   hipFree(s->u); hipFree(s->h); hipFree(s->ao); hipFree(s->ff); hipFree(s->q); hipFree(s->part);
-  hipFree(s->tr_out); hipFree(s->a0); hipFree(s->pcm_dbg); hipFree(s->rope);
+  hipFree(s->tr_out); hipFree(s->a0); hipFree(s->pcm_dbg); hipFree(s->pcm_part); hipFree(s->pcm_carry); hipFree(s->rope);
   for (int i = 0; i < 3; ++i) { hipFree(s->cbuf[i]); hipFree(s->craw[i]); hipFree(s->rbuf[i]); hipFree(s->sbuf[i]); }
   delete s;
 }
@@ -2320,6 +2329,7 @@ extern "C" int ptts_mimi_state_reset_row(ptts_mimi_state *s, int32_t row, void *
       HIPCHK(zero_block(s->cbuf[i], s->c_stride[i], par, e_a0));
       HIPCHK(zero_block(s->sbuf[i], s->s_stride[i], par, (f8 && i == 2) ? 2 : e_a0));
     }
+    if (s->pcm_carry && s->rows[3] % 64 == 0) HIPCHK(zero_block(s->pcm_carry, s->pcm_cstride, par, 4));  // the row's tile carries
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -2543,6 +2553,7 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
   }
   // SEANet decoder (seanet.py:141-180) as implicit GEMMs over (sequence, time) rows
   int mult = 8;
+  bool fused_pcm = false;
   SITE("seanet.conv0");
   a = mk_gemm(e->conv0, s->tr_out, CF, s->MT16, M16);
   a.Xdstride = s->tr_stride; a.T = s->rows[0]; a.par = s->frame;
@@ -2581,6 +2592,15 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
       // a split-bf16 engine keeps the FUSED fp32 residual blocks: the unfused split pair is slower (stage 3: 34 + 35 us
       // against 43 us fused, stage 2: 25 + 21 against 32; gpurun_out r3 profile), the block is bound by its activations
       a.W = e->res_a[i].w; a.Wq = nullptr; a.wfmt = 0;
+      // last stage: SEANet's final conv (k = 3, n_filters -> 1 sample) rides in the block's epilogue: the block's output
+      // (31 MB per 64-sequence frame, written and read back by a separate conv before) never leaves the CU
+      const Lin &CL = e->conv_last;
+      fused_pcm = e->opt_fuse_pcm && i == 2 && e->res_a[i].NT == 2 && Tout % 64 == 0 && MTout % 4 == 0 && cout == 64 &&
+                  CL.ntaps == 3 && CL.NT == 1 && !CL.wq && !CL.wb16 && !g_use_split && s->pcm_carry;
+      if (fused_pcm) {
+        a.pcm_w = CL.w; a.pcm_part = s->pcm_part; a.pcm_carry = s->pcm_carry; a.pcm_cstride = s->pcm_cstride;
+        if (!e->opt_debug_taps) a.Y = nullptr;
+      }
       launch_resblock(st, a, e->res_b[i], pre_a);
       xin = s->sbuf[i];
       xds = s->s_stride[i];
@@ -2605,10 +2625,16 @@ static int mimi_enqueue(hipStream_t st, ptts_engine *e, ptts_mimi_state *s, cons
   }
   const int Tl = s->rows[3];
   SITE("seanet.conv_last");
-  a = mk_gemm(e->conv_last, xin, c.n_filters / 16, B * Tl / 16, B * Tl);
-  a.Xdstride = xds; a.T = Tl; a.par = s->frame;
-  a.epi = EPI_PCM; a.pcm = d_pcm ? d_pcm : s->pcm_dbg; a.pcm_i16 = s->pcm_i16;
-  launch_gemm(st, a, PRE_NONE);
+  if (fused_pcm) {
+    ProfScope ps(st, "pcm_fix", 4.0 * (2.0 * B * Tl + B * Tl / 32.0), 0);
+    pcm_fix_kernel<<<cdiv(B * Tl, 256), 256, 0, st>>>(s->pcm_part, s->pcm_carry, s->pcm_cstride, s->frame, e->conv_last.bias,
+                                                      d_pcm ? d_pcm : s->pcm_dbg, s->pcm_i16, B * Tl, Tl / 64);
+  } else {
+    a = mk_gemm(e->conv_last, xin, c.n_filters / 16, B * Tl / 16, B * Tl);
+    a.Xdstride = xds; a.T = Tl; a.par = s->frame;
+    a.epi = EPI_PCM; a.pcm = d_pcm ? d_pcm : s->pcm_dbg; a.pcm_i16 = s->pcm_i16;
+    launch_gemm(st, a, PRE_NONE);
+  }
   SITE("mimi.tail");
   {
     ProfScope ps(st, "step_tail", 8.0 * B, 0);
@@ -3021,6 +3047,8 @@ extern "C" int ptts_set_option(ptts_engine *e, const char *key, int32_t value) {
   else if (k == "fuse_res") e->opt_fuse_res = value != 0;
   else if (k == "share_prefix") e->opt_share_prefix = value != 0;
   else if (k == "single_store") e->opt_single_store = value != 0;
+  else if (k == "fuse_pcm") e->opt_fuse_pcm = value != 0;
+  else if (k == "debug_taps") e->opt_debug_taps = value != 0;
   else if (k == "prefix_cascade") e->opt_cascade = value == 1 ? 423 : value;
   else if (k == "codec_lds_target") {
     if (value < 0 || value > 64 * 1024) return fail(-1, "codec_lds_target must be in [0, 65536]");
@@ -3175,6 +3203,8 @@ extern "C" int64_t ptts_debug_read(ptts_engine *e, void *state, int32_t is_mimi,
       K = mult * c.n_filters / 2;
       M = B * s->rows[stage + 1];
       const ptts_engine *en = s->e;
+      if (is_res && stage == 2 && en->opt_fuse_pcm && !en->opt_debug_taps && !en->codec_split && en->res_a[2].NT == 2 && s->rows[3] % 64 == 0)
+        return fail(-1, "debug_read: " + n + " stays on chip with \"fuse_pcm\"; set the engine option \"debug_taps\" before decoding");
       const bool single = en->opt_single_store && !en->codec_split && !en->res_a[stage].wq && !en->res_a[stage].wb16;
       src = is_res ? s->sbuf[stage] + par * s->s_stride[stage] : single ? s->cbuf[stage] + par * s->c_stride[stage] : s->craw[stage];
     }

@@ -184,6 +184,12 @@ struct GemmArgs {
   // EPI_PCM
   float *pcm;
   int16_t *pcm_i16;  // optional 16-bit copy: (clamp(x, -1, 1) * 32767) truncated, as data/audio.py:79
+  // fused residual block of the LAST stage + SEANet's last conv (k taps, n_filters -> 1 sample): the block's output tile
+  // never leaves the CU.  pcm_w = the last conv's packed weights (NT = 1), pcm_part[row] = the taps whose rows lie in this
+  // workgroup's 64 rows, pcm_carry[parity][tile][2] = what rows 0 and 1 of the NEXT tile still miss (pcm_fix_kernel adds them)
+  const float *pcm_w;
+  float *pcm_part, *pcm_carry;
+  long pcm_cstride;  // floats between the two frame parities of pcm_carry
 };
 
 // Workgroup -> tile mapping.  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs (ids b and
@@ -850,6 +856,26 @@ static __global__ __launch_bounds__(256) void pcm_conv_kernel(GemmArgs a) {
   }
 }
 
+// Final PCM of the fused (residual block + last conv) path: row u of a 64-row tile adds what the PREVIOUS tile of the same
+// sequence left for it (rows 0 and 1 only; the first tile of a frame takes the last tile of the previous frame from the
+// other parity, zero on a sequence's first frame) and the bias, and writes fp32 (+ int16) PCM - straight into the caller's
+// (pinned host) buffer like pcm_conv_kernel.
+static __global__ void pcm_fix_kernel(const float *part, const float *carry, long cstride, const int *parp, const float *bias,
+                                      float *pcm, int16_t *pcm_i16, int M, int tps) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= M) return;
+  const int par = parp ? (*parp & 1) : 0;
+  const int u = row & 63, tile = row >> 6;
+  float v = part[row] + (bias ? bias[0] : 0.f);
+  if (u < 2) {
+    const bool first = tile % tps == 0;
+    const float *c = carry + (first ? (par ^ 1) : par) * cstride + (size_t)(first ? tile + tps - 1 : tile - 1) * 2;
+    v += c[u];
+  }
+  pcm[row] = v;
+  if (pcm_i16) pcm_i16[row] = (int16_t)(fminf(fmaxf(v, -1.0f), 1.0f) * 32767.0f);
+}
+
 // ---------------------------------------------------------------------------------------------
 // LDS-staged variant for the large-M GEMMs of the codec (rows = sequences x time).  A workgroup of 4 waves
 // (2 x 2) owns BMT x BNT 16x16 tiles.  Per stage of KC k-fragments every operand fragment is copied ONCE per
@@ -1089,7 +1115,51 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
 #pragma unroll
           for (int cidx = 0; cidx < 4; ++cidx)
             c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[t][k][cidx], x[k][cidx], c2, 0, 0, 0);
+        if constexpr (NT2 == 4) {
+          if (a.pcm_w) {
+            // == gemm_epilogue(EPI_RES) without the store: z = act2(skip + conv + bias) stays in registers, and its three
+            // last-conv taps are dotted over this lane's 4 channels, then over the 16 channels of the wave's column tile
+            const int nt = wave, g = lane >> 4;
+            const int n0 = 16 * nt + 4 * g;
+            f32x4 v = c2 + *(const f32x4 *)(a2.bias + n0);
+            v = act4(*(const f32x4 *)(a.R + par * a.Rdstride + (((size_t)mt * a.RF + nt) * 64 + lane) * 4) + v, a2.act);
+            if (a.Y) *(f32x4 *)(a.Y + par * a.Ydstride + (((size_t)mt * a.YF + nt) * 64 + lane) * 4) = v;  // debug taps only
+            float *pp = (float *)&lds[0][BMT * BNT][0];  // [wave][m][tap][16 rows], behind the h tile
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              const f32x4 wd = *(const f32x4 *)(a.pcm_w + ((size_t)(d * 4 + nt) * 64 + 16 * g) * 4);
+              float p = (v.x * wd.x + v.y * wd.y) + (v.z * wd.z + v.w * wd.w);
+              p += __shfl_xor(p, 16);
+              p += __shfl_xor(p, 32);
+              if (lane < 16) pp[((wave * BMT + m) * 3 + d) * 16 + lane] = p;
+            }
+            continue;
+          }
+        }
         gemm_epilogue(a2, c2, wave + 4 * t, mt, lane, par);
+      }
+    }
+    if constexpr (NT2 == 4) {
+      if (a.pcm_w) {
+        __syncthreads();
+        if (wave != 0) return;
+        // lane = row of the workgroup's 64; S_d = tap d's dot product over all 64 channels of that row;
+        // pcm[u] = bias + S_2[u] + S_1[u - 1] + S_0[u - 2] (causal, reference conv.py:84-91 with k = 3)
+        const float *pp = (const float *)&lds[0][BMT * BNT][0];
+        const int m = lane >> 4, ml = lane & 15;
+        float sd[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          sd[d] = (pp[((0 * BMT + m) * 3 + d) * 16 + ml] + pp[((1 * BMT + m) * 3 + d) * 16 + ml]) +
+                  (pp[((2 * BMT + m) * 3 + d) * 16 + ml] + pp[((3 * BMT + m) * 3 + d) * 16 + ml]);
+        const float s1u = __shfl_up(sd[1], 1), s0u = __shfl_up(sd[0], 2), s0v = __shfl_up(sd[0], 1);
+        const size_t row = (size_t)16 * mt0 + lane;
+        if (16 * mt0 + lane < a.M) a.pcm_part[row] = sd[2] + (lane >= 1 ? s1u : 0.f) + (lane >= 2 ? s0u : 0.f);
+        if (lane == 63) {  // what the next tile's rows 0 and 1 miss
+          float *c = a.pcm_carry + par * a.pcm_cstride + (size_t)(mt0 / BMT) * 2;
+          c[0] = sd[1] + s0v;
+          c[1] = sd[0];
+        }
       }
     }
     return;

@@ -179,3 +179,48 @@ def test_24l_batch32_vs_oracle():
     finally:
         st.close()
         ms.close()
+
+
+@pytest.mark.parametrize("B", [3, 64])
+def test_fused_last_conv_matches_separate_conv(B):
+    """"fuse_pcm" (SEANet's last conv inside the last stage's fused residual block: per-tile partial sums + a carry for the
+    first two samples of the next 64-row tile, across tiles, frames and a row reset) against the separate last conv reading
+    the stored block output: same PCM to fp32 summation order, fp32 and int16, and a stage-3 tap refuses to be read while
+    it stays on chip.  The goldens / oracle comparisons of the other tests run on the fused path (the default)."""
+    from pocket_tts_amd._lib import PttsError
+    from pocket_tts_amd.engine import Engine
+
+    cfg, W = synth_weights("en100m")
+    eng = Engine(cfg, W, "cuda:0")
+    rng = np.random.default_rng(21)
+    nf = 5
+    lat = rng.standard_normal((nf, B, cfg.mimi.quantizer.dimension)).astype(np.float32)
+    outs = []
+    try:
+        for fuse in (0, 1):
+            eng.set_option("fuse_pcm", fuse)
+            ms = eng.new_mimi_state(B)
+            i16 = torch.zeros((B, eng.frame_samples), dtype=torch.int16, device="cuda:0")
+            ms.set_pcm_i16(i16)
+            got = []
+            for f in range(nf):
+                if f == 3:
+                    ms.reset_row(B - 1)  # continuous batching: the row's carries (conv inputs AND tile carries) are cleared
+                pcm = eng.mimi_decode(ms, dev(lat[f % 3 if f >= 3 else f]))
+                torch.cuda.synchronize()
+                got.append((pcm.cpu().numpy().copy(), i16.cpu().numpy().copy()))
+            if fuse:
+                with pytest.raises(PttsError, match="debug_taps"):
+                    eng.debug_read(ms, "seanet9")
+            outs.append(got)
+            ms.close()
+    finally:
+        eng.close()
+    worst = 0.0
+    for (p0, i0), (p1, i1) in zip(*outs):
+        worst = max(worst, float(np.abs(p0 - p1).max()))
+        assert np.abs(i0.astype(np.int32) - i1.astype(np.int32)).max() <= 1
+    print(f"B={B}: fused vs separate last conv, max abs PCM difference {worst:.2e}")
+    assert worst < 2e-6, worst
+    # after the reset, the reset row reproduces its own first frames (tile carries really cleared)
+    assert np.abs(outs[1][3][0][B - 1] - outs[1][0][0][B - 1]).max() < 2e-6
