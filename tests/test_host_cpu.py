@@ -135,6 +135,11 @@ def test_pmc_tool_labels_match_the_profiler_labels():
     assert n("void gemm_kernel<1, 1, 4, 1, 1, 0, 2>(GemmArgs)") == "gemm<1,1,4,1,1>+b16"
     assert n("void gemm_lds_kernel<4, 4, 2, 3, 2>(GemmArgs)") == "gemm_lds<4,4,2>+ln"
     assert n("void gemm_lds_kernel<4, 2, 2, 0, 2>(GemmArgs)") == "gemm_lds<4,2,2>"
+    assert n("void gemm_lds_kernel<4, 4, 2, 1, 3, 0>(GemmArgs)") == "gemm_lds<4,4,2>+elu"       # operand ELU on read (single store)
+    assert n("void gemm_lds_kernel<4, 2, 2, 1, 2, 4>(GemmArgs)") == "resblock<2,4>+elu"        # fused residual block, same
+    assert n("void gemm_lds_kernel<4, 4, 2, 0, 2, 8>(GemmArgs)") == "resblock<4,8>"
+    assert n("void attn_cascade_kernel<4, 2, 3, 1>(AttnArgs)") == "attn_cascade"
+    assert n("pcm_fix_kernel(float const*, float const*, long, int const*, float const*, float*, short*, int, int)") == "pcm_fix"
     assert n("void attn_decode_kernel<1, true>(AttnArgs)") == "attn_decode"
     assert n("attn_kernel(AttnArgs)") == "attn"
     assert n("attn_combine_kernel(AttnArgs)") == "attn_combine"

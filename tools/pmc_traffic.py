@@ -24,7 +24,7 @@ def norm(name):
     m = re.search(r"gemm_lds_kernel<(\d+), (\d+), (\d+), (\d+)(?:, (\d+))?(?:, (\d+))?>", name)
     if m:
         if m.group(6) and int(m.group(6)) > 0:  # fused residual block: bench.py's profiler calls it resblock<BNT,NT2>
-            return "resblock<%s,%s>" % (m.group(2), m.group(6))
+            return "resblock<%s,%s>%s" % (m.group(2), m.group(6), PRE.get(int(m.group(4)), ""))
         return "gemm_lds<%s,%s,%s>%s" % (m.group(1), m.group(2), m.group(3), PRE.get(int(m.group(4)), ""))
     if "attn_decode" in name:
         return "attn_decode"
