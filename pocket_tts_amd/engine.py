@@ -312,6 +312,10 @@ class Engine:
             # ceil(tokens / 16) only (chunks hold <= 50 tokens + padding)
             for t in (16, 32, 48, 64):
                 _lib.check(self.lib.ptts_tune_prefill(self.handle, 1, t, self._sp))
+        elif os.environ.get("PTTS_TUNE_PREFILL_TOKENS"):
+            # batched prefill (a group of requests with one token count): GEMMs of batch x ceil(tokens / 16) row tiles
+            for t in os.environ["PTTS_TUNE_PREFILL_TOKENS"].split(","):
+                _lib.check(self.lib.ptts_tune_prefill(self.handle, int(batch), int(t), self._sp))
         self._tuned.add(batch)
         after = self._tune_table()
         new = [ln for ln in after if ln not in before]
