@@ -2301,6 +2301,7 @@ extern "C" int ptts_mimi_state_reset(ptts_mimi_state *s, void *stream) {
     HIPCHK(hipMemsetAsync(s->sbuf[i], 0, (size_t)2 * s->s_stride[i] * 4, st));
   }
   HIPCHK(hipMemsetAsync(s->kv, 0, (size_t)s->e->cfg.m_layers * 2 * s->kv_plane() * 4, st));
+  if (s->pcm_carry) HIPCHK(hipMemsetAsync(s->pcm_carry, 0, (size_t)2 * s->pcm_cstride * 4, st));  // the fused last conv's tile carries
   s->h_frame = 0;
   return 0;
 }

@@ -212,6 +212,9 @@ def test_fused_last_conv_matches_separate_conv(B):
             if fuse:
                 with pytest.raises(PttsError, match="debug_taps"):
                     eng.debug_read(ms, "seanet9")
+            ms.reset()  # a new utterance batch on the same state: every carry cleared, frame 0 reproduces itself
+            again = eng.mimi_decode(ms, dev(lat[0])).cpu().numpy()
+            assert np.abs(again - got[0][0]).max() < 2e-6, ("reset", fuse)
             outs.append(got)
             ms.close()
     finally:
@@ -224,3 +227,29 @@ def test_fused_last_conv_matches_separate_conv(B):
     assert worst < 2e-6, worst
     # after the reset, the reset row reproduces its own first frames (tile carries really cleared)
     assert np.abs(outs[1][3][0][B - 1] - outs[1][0][0][B - 1]).max() < 2e-6
+
+
+def test_en100m_states_reused_across_utterances():
+    """the streaming and batch paths keep their states, scratch and graphs between calls: a second utterance (and a second
+    batch) on the reused states must equal the first - every carry of the previous utterance (conv inputs, KV ring, the fused
+    last conv's tile carries, borrowed voice prefixes) cleared or re-established"""
+    from pocket_tts_amd import TTSModel
+
+    G = Path(__file__).parent / "golden"
+    m = TTSModel.load_model(config=G / "e2e2_en100m.yaml", temp=0.0)
+    try:
+        st = m.get_state_for_conditioning(torch.randn(1, 12, 1024, generator=torch.Generator().manual_seed(3)) * 0.1)
+        text = "Hello world. This is a test."
+        a = m.generate_audio(st, text, frames_after_eos=2).numpy()
+        other = m.generate_audio(st, "Another one.", frames_after_eos=2).numpy()
+        b = m.generate_audio(st, text, frames_after_eos=2).numpy()
+        assert a.shape == b.shape and a.shape[0] >= 1920 and other.shape[0] >= 1920
+        assert np.abs(a - b).max() < 1e-6
+        texts = [text, "Another one.", text]
+        w1 = m.generate_audio_batch(st, texts, frames_after_eos=2)
+        w2 = m.generate_audio_batch(st, texts, frames_after_eos=2)
+        for x, y in zip(w1, w2):
+            assert x.shape == y.shape and np.abs(x.numpy() - y.numpy()).max() < 1e-6
+        assert w1[0].shape == a.shape and np.abs(w1[0].numpy() - a).max() < 5e-4  # batch row == single utterance
+    finally:
+        m.engine.close()
