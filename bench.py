@@ -768,7 +768,10 @@ def main():
             job1 = None
         job_one = None
         if world == 1 and args.voices == "distinct" and args.batch >= 16 and not args.quick:
-            out["one_voice"], job_one = one_voice_throughput(eng, args, n_utt, rank, out["tune_table_id"], not args.no_profile)
+            try:  # a secondary leg must not cost the headline line
+                out["one_voice"], job_one = one_voice_throughput(eng, args, n_utt, rank, out["tune_table_id"], not args.no_profile)
+            except Exception as e1:  # noqa: BLE001
+                out["one_voice"] = {"error": f"{type(e1).__name__}: {e1}"}
         if not args.no_api and world == 1 and args.preset in ("headline", "b1") and args.config != "24l" and args.batch > 1:
             if job_one is None:
                 a1v = argparse.Namespace(**vars(args))
