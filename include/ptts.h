@@ -134,6 +134,12 @@ int ptts_lm_state_offsets(ptts_lm_state *s, int32_t *h_offsets, void *stream);
  * is kept.  Replaces _run_flow_lm_and_increment_step(text_tokens=.. | audio_conditioning=..)
  * (tts_model.py:317-346, call sites :723, :899). */
 int ptts_lm_prefill(ptts_engine *e, ptts_lm_state *s, const float *d_emb, int32_t t, void *stream);
+/* The text-embedding gather in front of a text prefill (LUTConditioner._get_condition, conditioners/text.py:74-76):
+ * d_out f32[n, d_model] <- d_table[d_tokens[i]] for int64 ids; d_table = the checkpoint tensor
+ * "flow_lm.conditioner.embed.weight" f32[n_bins, d_model], which stays the caller's.  Asynchronous on `stream`; an id outside
+ * [0, n_bins) gives a zero row (validate ids on the host, where the tokenizer made them). */
+int ptts_embed_tokens(ptts_engine *e, const float *d_table, int32_t n_bins, const int64_t *d_tokens, int64_t n,
+                      float *d_out, void *stream);
 
 /* One autoregressive step = _run_flow_lm_and_increment_step(backbone_input_latents=..)
  * (tts_model.py:758-760 -> flow_lm.py:96-139).

@@ -92,6 +92,7 @@ PROTOTYPES = {
     "ptts_sync": (C.c_int, [_P, _P]),
     "ptts_engine_stream": (_P, [_P]),
     "ptts_copy_to_host_async": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "ptts_embed_tokens": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int64, _P, _P]),
     "ptts_timer_start": (C.c_int, [_P, _P]),
     "ptts_timer_stop_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     "ptts_debug_read": (C.c_int64, [_P, _P, C.c_int32, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int32),

@@ -3146,6 +3146,20 @@ extern "C" int ptts_sync(ptts_engine *e, void *stream) {
   return 0;
 }
 extern "C" void *ptts_engine_stream(ptts_engine *e) { return (void *)e->stream; }
+// Text-embedding gather of the prefill (reference text.py:74-76, tts_model.py:722-725): d_out[i, :] = d_table[d_tokens[i], :].
+// The table stays the caller's tensor (checkpoint "flow_lm.conditioner.embed.weight", f32[n_bins, d_model]).  Asynchronous;
+// ids outside [0, n_bins) give zero rows (callers validate ids on the host, where the tokenizer produced them).
+extern "C" int ptts_embed_tokens(ptts_engine *e, const float *d_table, int32_t n_bins, const int64_t *d_tokens, int64_t n,
+                                 float *d_out, void *stream) {
+  if (!e || !d_table || !d_tokens || !d_out || n < 0 || n_bins < 1) return fail(-1, "embed_tokens: bad argument");
+  if (n == 0) return 0;
+  ENGINE_LOCK(e);
+  HIPCHK(hipSetDevice(e->device));
+  const int D = e->cfg.d_model;
+  embed_gather_kernel<<<cdiv(n * (D / 4), 256), 256, 0, S(e, stream)>>>(d_table, n_bins, D, (const long long *)d_tokens, n, d_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 extern "C" int ptts_copy_to_host_async(ptts_engine *e, void *h_dst, const void *d_src, int64_t bytes, void *stream) {
   HIPCHK(hipMemcpyAsync(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, S(e, stream)));
   return 0;

@@ -1546,6 +1546,19 @@ static __global__ void set_prefix_kernel(KvPrefix *p, int n, const float *kv, in
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = KvPrefix{kv, cap, len};
 }
+// LUTConditioner._get_condition (reference text.py:74-76): out[i] = table[tokens[i]], one float4 per thread; an id outside
+// the table yields a zero row (the host checks the ids before the call)
+static __global__ void embed_gather_kernel(const float *table, int n_bins, int D, const long long *tokens, long n, float *out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int d4 = D / 4;
+  if (i >= n * d4) return;
+  const long r = i / d4;
+  const int c = (int)(i - r * d4);
+  const long long t = tokens[r];
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (t >= 0 && t < n_bins) v = *(const f32x4 *)(table + (size_t)t * D + 4 * c);
+  *(f32x4 *)(out + (size_t)r * D + 4 * c) = v;
+}
 static __global__ void set_int_kernel(int *p, int n, int v) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;

@@ -381,8 +381,20 @@ class Engine:
 
     # ---- FlowLM
     def embed_text(self, tokens: torch.Tensor) -> torch.Tensor:
-        """`LUTConditioner._get_condition` gather (reference text.py:74-76); prefill input only."""
-        return self.embed[tokens.to(self.device)]
+        """`LUTConditioner._get_condition` gather (reference text.py:74-76); prefill input only.  tokens: int64 [B, T]
+        (host or device); ids are validated where they are cheap to read, the gather itself is `ptts_embed_tokens`."""
+        tokens = tokens.to(torch.int64)
+        if tokens.device.type == "cpu" and tokens.numel() and (int(tokens.min()) < 0 or int(tokens.max()) >= self.embed.shape[0]):
+            raise IndexError("index out of range in self")  # torch.nn.Embedding's message (reference LUT conditioner)
+        tok = tokens.to(self.device).contiguous()
+        out = torch.empty((*tok.shape, self.D), dtype=torch.float32, device=self.device)
+        self._pre()
+        _lib.check(self.lib.ptts_embed_tokens(self.handle, _ptr(self.embed), int(self.embed.shape[0]), _ptr(tok), tok.numel(),
+                                              _ptr(out), self._sp))
+        tok.record_stream(self.stream)
+        out.record_stream(self.stream)
+        self._post()
+        return out
 
     def lm_prefill(self, state: LMState, emb: torch.Tensor):
         """emb f32[B, T, D]: text embeddings or voice conditioning (reference tts_model.py:722-725,899)."""

@@ -253,3 +253,17 @@ def test_en100m_states_reused_across_utterances():
         assert w1[0].shape == a.shape and np.abs(w1[0].numpy() - a).max() < 5e-4  # batch row == single utterance
     finally:
         m.engine.close()
+
+
+def test_embedding_gather_is_the_table_lookup():
+    """`ptts_embed_tokens` (LUTConditioner._get_condition, reference text.py:74-76) == indexing the table, bit for bit; ids
+    outside the table raise on the host like torch.nn.Embedding"""
+    eng = get_engine("tiny")
+    n = eng.embed.shape[0]
+    tok = torch.randint(0, n, (3, 37), generator=torch.Generator().manual_seed(0))
+    got = eng.embed_text(tok)
+    torch.cuda.synchronize()
+    assert got.shape == (3, 37, eng.D) and torch.equal(got, eng.embed[tok.to("cuda:0")])
+    assert torch.equal(eng.embed_text(tok.to("cuda:0")), got)  # device-resident ids (bench.py)
+    with pytest.raises(IndexError):
+        eng.embed_text(torch.tensor([[0, n]]))
