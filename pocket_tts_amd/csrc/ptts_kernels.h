@@ -2402,7 +2402,7 @@ static __global__ void kv_export_kernel(float *dst, const float *Kc, const float
   *(f32x4 *)(dst + ((((size_t)which * B + b) * T + t) * H + h) * 64 + d4 * 4) = v;
 }
 
-// dst rows <- src rows (src batch 1 broadcasts), whole [L][2][B][H][cap][64] block, equal cap
+// dst rows <- src rows (src batch 1 broadcasts) of a [L][2][B][H][cap][64] cache block
 // one batch-1 state -> row `row` of a batch state: [planes][1][H][src_cap][64] -> [planes][B][H][dst_cap][64], T positions
 static __global__ void kv_copy_row_kernel(float *dst, const float *src, int planes, int H, int T, int src_cap, int dst_cap,
                                    int B, int row, int srcB = 1, int src_row = 0, int t0 = 0) {
@@ -2417,15 +2417,18 @@ static __global__ void kv_copy_row_kernel(float *dst, const float *src, int plan
   *(f32x4 *)(dst + ((((size_t)pl * B + row) * H + h) * dst_cap + t) * 64 + v * 4) = x;
 }
 
-static __global__ void kv_copy_kernel(float *dst, const float *src, long per_row, int B, int srcB, int planes) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // float4 units over [planes][B][per_row/4]
-  long pr4 = per_row / 4;
-  long total = (long)planes * B * pr4;
-  if (i >= total) return;
-  long e = i % pr4;
-  long r = i / pr4;
-  int b = r % B;
-  int pl = r / B;
-  int sb = srcB == 1 ? 0 : b;
-  *(f32x4 *)(dst + ((size_t)pl * B + b) * per_row + e * 4) = *(const f32x4 *)(src + ((size_t)pl * srcB + sb) * per_row + e * 4);
+// dst rows <- src rows (src batch 1 broadcasts) of a [L][2][B][H][cap][64] cache block: the first T positions (a clone needs
+// the written part of the cache, not its whole capacity), any two capacities
+static __global__ void kv_copy_t_kernel(float *dst, const float *src, int planes, int B, int srcB, int H, int T, int src_cap, int dst_cap) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // float4 units over [planes][B][H][T][16]
+  if (i >= (long)planes * B * H * T * 16) return;
+  const int v = i & 15;
+  long r = i >> 4;
+  const int t = r % T; r /= T;
+  const int h = r % H; r /= H;
+  const int b = r % B;
+  const int pl = r / B;
+  const int sb = srcB == 1 ? 0 : b;
+  *(f32x4 *)(dst + ((((size_t)pl * B + b) * H + h) * dst_cap + t) * 64 + v * 4) =
+      *(const f32x4 *)(src + ((((size_t)pl * srcB + sb) * H + h) * src_cap + t) * 64 + v * 4);
 }
