@@ -862,11 +862,11 @@ static int attn_splits(int base, int max_tiles) {
   int s = std::max(1, cdiv(attn_wave_target(), std::max(1, base * nw)));
   return std::max(1, std::min(s, tiles));
 }
-// attn_cascade_kernel<R, PW, D, NS> shapes selectable with "prefix_cascade" / PTTS_CASCADE (default <4, 2, 3, 1>: measured in
-// profiles/r03_experiments.txt; more waves per workgroup or deeper register rings lose beside the codec stream)
+// attn_cascade_kernel<R, PW, D, NS> shapes selectable with "prefix_cascade" / PTTS_CASCADE besides the default <4, 2, 3, 1>
+// (the parity tests run these; all shapes measured are in profiles/r03_experiments.txt: more waves per workgroup or a fourth
+// register tile lose beside the codec stream)
 #define CASC_SHAPES \
-  CASC(442, 4, 4, 2, 2) CASC(422, 4, 2, 2, 2) CASC(222, 2, 2, 2, 2) CASC(443, 4, 4, 3, 1) CASC(413, 4, 1, 3, 1) CASC(424, 4, 2, 4, 1) \
-  CASC(823, 8, 2, 3, 1) CASC(213, 2, 1, 3, 1) CASC(42, 4, 2, 2, 1) CASC(44, 4, 4, 2, 1) CASC(84, 8, 4, 2, 1) CASC(22, 2, 2, 2, 1)
+  CASC(442, 4, 4, 2, 2) CASC(222, 2, 2, 2, 2) CASC(42, 4, 2, 2, 1) CASC(44, 4, 4, 2, 1) CASC(84, 8, 4, 2, 1) CASC(22, 2, 2, 2, 1)
 static void launch_attn(hipStream_t st, const AttnArgs &at, int BH) {
   const dim3 grid(BH, at.QB, at.splits);
   const int nw = attn_nw(BH * at.QB);
