@@ -1711,6 +1711,16 @@ extern "C" int ptts_lm_state_copy(ptts_lm_state *dst, const ptts_lm_state *src, 
       const long total = (long)c.num_layers * 2 * dst->B * c.num_heads * T * 16;
       kv_copy_t_kernel<<<cdiv(total, 256), 256, 0, st>>>(dst->kv, src->kv, c.num_layers * 2, dst->B, src->B, c.num_heads, T, src->cap, dst->cap);
     }
+  } else if (src->B == 1 && !src->pre_owner[0] && !src->zombie && dst->e->opt_share_prefix && !dst->e->opt_lm_cluster && T >= 16) {
+    // the common case, a plain voice state cloned into every row: all rows borrow its first T & ~15 positions and ONE
+    // kernel copies the (< 16) positions behind them
+    ptts_lm_state *owner = const_cast<ptts_lm_state *>(src);
+    const int plen = T & ~15;
+    for (int b = 0; b < dst->B; ++b) prefix_borrow(dst, b, owner, plen);
+    if (T > plen) {
+      const long total = (long)c.num_layers * 2 * dst->B * c.num_heads * (T - plen) * 16;
+      kv_copy_t_kernel<<<cdiv(total, 256), 256, 0, st>>>(dst->kv, src->kv, c.num_layers * 2, dst->B, 1, c.num_heads, T - plen, src->cap, dst->cap, plen);
+    }
   } else {
     // row by row: one copy kernel per destination row for the positions it does not share
     for (int b = 0; b < dst->B; ++b) {

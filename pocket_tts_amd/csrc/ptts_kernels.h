@@ -2419,12 +2419,13 @@ static __global__ void kv_copy_row_kernel(float *dst, const float *src, int plan
 
 // dst rows <- src rows (src batch 1 broadcasts) of a [L][2][B][H][cap][64] cache block: the first T positions (a clone needs
 // the written part of the cache, not its whole capacity), any two capacities
-static __global__ void kv_copy_t_kernel(float *dst, const float *src, int planes, int B, int srcB, int H, int T, int src_cap, int dst_cap) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // float4 units over [planes][B][H][T][16]
+static __global__ void kv_copy_t_kernel(float *dst, const float *src, int planes, int B, int srcB, int H, int T, int src_cap, int dst_cap,
+                                        int t0 = 0) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // float4 units over [planes][B][H][T][16], positions t0 .. t0 + T - 1
   if (i >= (long)planes * B * H * T * 16) return;
   const int v = i & 15;
   long r = i >> 4;
-  const int t = r % T; r /= T;
+  const int t = t0 + r % T; r /= T;
   const int h = r % H; r /= H;
   const int b = r % B;
   const int pl = r / B;
