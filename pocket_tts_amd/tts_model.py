@@ -339,7 +339,8 @@ class TTSModel:
             n = int(n_emit[b]) if n_emit[b] >= 0 else gens[b]
             if eos_step[b] < 0:
                 logger.warning("Maximum generation length reached without EOS, this very often indicates an error.")
-            res.append(torch.from_numpy(out[b, :n].reshape(-1).copy()) if n > 0 else torch.zeros(0))
+            # a view of this call's own frame buffer (allocated per call, so nothing rewrites it): no second copy of the audio
+            res.append(torch.from_numpy(out[b, :n].reshape(-1)) if n > 0 else torch.zeros(0))
         return res
 
     def _drop_batch_contexts(self, keep: int = 0):
