@@ -119,7 +119,7 @@ def test_owner_destroyed_rows_parked_and_lent_state_guarded():
 
 @pytest.mark.parametrize("cfg_name,B,T0,T1,shape", [("tiny", 16, 37, 5, 44), ("tiny", 19, 100, 3, 42), ("en100m", 64, 126, 32, 44),
                                                     ("en100m", 33, 126, 32, 84), ("en100m", 18, 47, 9, 22), ("en100m", 21, 126, 32, 442),
-                                                    ("tiny", 17, 50, 4, 222)])
+                                                    ("tiny", 17, 50, 4, 222), ("tiny", 16, 523, 41, 1), ("en100m", 16, 600, 50, 1)])
 def test_cascade_attention_matches_per_sequence_attention(cfg_name, B, T0, T1, shape):
     """decode steps with the prefix as shared MFMA tiles == every sequence on its own, to fp32 summation order; groups
     that overhang the batch, a parked row and a row re-admitted from ANOTHER voice (its group falls back to the
